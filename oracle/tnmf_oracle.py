@@ -20,7 +20,10 @@ All shapes:  V[n, c, *D]   W[m, c, *A]   H[n, m, *D']   with 'valid' mode D' = D
 """
 from __future__ import annotations
 
+import ctypes
 import enum
+import os
+import subprocess
 from itertools import islice
 from typing import Callable, Iterable, Optional, Sequence, Tuple
 
@@ -28,6 +31,78 @@ import numpy as np
 from numpy.lib.stride_tricks import sliding_window_view
 
 EPS = 1.0e-9  # TransformInvariantNMF.py:166
+
+
+# ----------------------------------------------------------------------------------------------------------
+# optional C flavour (oracle/tnmf_oracle_c.c): same index forms as plain loops, OpenMP, double accumulation.
+# Pinned by the same golden vectors; used where the NumPy windows+contraction form is too slow for a test.
+# ----------------------------------------------------------------------------------------------------------
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CLIB_PATH = os.path.join(_HERE, '_build', 'libtnmf_oracle.so')
+_clib = None
+
+
+def build_c(force: bool = False) -> str:
+    """Compile oracle/tnmf_oracle_c.c with gcc into oracle/_build/ (called by __graft_entry__.build())."""
+    src = os.path.join(_HERE, 'tnmf_oracle_c.c')
+    if force or not os.path.exists(_CLIB_PATH) or os.path.getmtime(_CLIB_PATH) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(_CLIB_PATH), exist_ok=True)
+        # no -march=native: the library is built in the build container and runs on the GPU box's host CPU
+        subprocess.check_call(['gcc', '-O3', '-fopenmp', '-shared', '-fPIC', src, '-o', _CLIB_PATH])
+    return _CLIB_PATH
+
+
+class _Geom(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int) for k in ('N', 'M', 'C', 'Dy', 'Dx', 'Ay', 'Ax')]
+
+
+def _c():
+    global _clib
+    if _clib is None:
+        # NumPy's BLAS pool and libgomp's pool would oversubscribe the cores with spinning waiters
+        os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
+        _clib = ctypes.CDLL(build_c())
+        _clib.oracle_set_threads(int(os.environ.get('OMP_NUM_THREADS', max(1, min(16, (os.cpu_count() or 2) // 2)))))
+    return _clib
+
+
+def _geom2d(N, M, C, D, A) -> _Geom:
+    if len(A) == 1:
+        return _Geom(N, M, C, 1, D[0], 1, A[0])
+    if len(A) == 2:
+        return _Geom(N, M, C, D[0], D[1], A[0], A[1])
+    raise NotImplementedError('C oracle handles 1-D and 2-D shifts only')
+
+
+def _c_call(name, dtype, g, *arrays):
+    suf = {np.dtype('float64'): 'f64', np.dtype('float32'): 'f32'}[np.dtype(dtype)]
+    fn = getattr(_c(), f'oracle_{name}_{suf}')
+    fn.restype = None
+    fn(ctypes.byref(g), *[a.ctypes.data_as(ctypes.c_void_p) for a in arrays])
+
+
+def _c_reconstruct(W, H):
+    W, H = np.ascontiguousarray(W), np.ascontiguousarray(H)
+    A = W.shape[2:]
+    D = tuple(h - a + 1 for h, a in zip(H.shape[2:], A))
+    R = np.empty((H.shape[0], W.shape[1]) + D, dtype=H.dtype)
+    _c_call('reconstruct', H.dtype, _geom2d(H.shape[0], W.shape[0], W.shape[1], D, A), W, H, R)
+    return R
+
+
+def _c_correlate_with_W(W, X):
+    W, X = np.ascontiguousarray(W), np.ascontiguousarray(X)
+    A, D = W.shape[2:], X.shape[2:]
+    out = np.empty((X.shape[0], W.shape[0]) + tuple(d + a - 1 for d, a in zip(D, A)), dtype=X.dtype)
+    _c_call('corr_with_W', X.dtype, _geom2d(X.shape[0], W.shape[0], W.shape[1], D, A), W, X, out)
+    return out
+
+
+def _c_correlate_H_with(X, H, A):
+    X, H = np.ascontiguousarray(X), np.ascontiguousarray(H)
+    out = np.empty((H.shape[1], X.shape[1]) + tuple(A), dtype=X.dtype)
+    _c_call('corr_H_with', X.dtype, _geom2d(X.shape[0], H.shape[1], X.shape[1], X.shape[2:], A), H, X, out)
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -79,11 +154,16 @@ def contract(x, x_idx, y, y_idx, out_idx):
     return np.einsum(x, x_idx, y, y_idx, out_idx, optimize=True)
 
 
-def reconstruct(W: np.ndarray, H: np.ndarray) -> np.ndarray:
+def reconstruct(W: np.ndarray, H: np.ndarray, impl: str = 'contract') -> np.ndarray:
     """
     R[n,c,d] = sum_m sum_a H[n,m,d+a] * W[m,c,A-1-a]   ('valid' part of the full convolution H (*) W).
     backends/NumPy.py:122-132 (windows :124-127, flipped W :130).
+    ``impl``: 'contract' (windows + one contraction, the reference's algorithm), 'shiftsum' or 'c'.
     """
+    if impl == 'c':
+        return _c_reconstruct(W, H)
+    if impl == 'shiftsum':
+        return reconstruct_shiftsum(W, H)
     k = W.ndim - 2
     A = W.shape[2:]
     Hw = sliding_window_view(H, A, axis=_shift_axes(k))          # [n, m, *D, *A]
@@ -98,8 +178,12 @@ def _pad_atoms(X: np.ndarray, A: Sequence[int]) -> np.ndarray:
     return np.pad(X, ((0, 0), (0, 0)) + tuple((a - 1, a - 1) for a in A))
 
 
-def _correlate_with_W(W: np.ndarray, X: np.ndarray) -> np.ndarray:
+def _correlate_with_W(W: np.ndarray, X: np.ndarray, impl: str = 'contract') -> np.ndarray:
     """out[n,m,u] = sum_c sum_a W[m,c,a] * Xpad[n,c,u+a].  backends/NumPy.py:101-109 / :111-119."""
+    if impl == 'c':
+        return _c_correlate_with_W(W, X)
+    if impl == 'shiftsum':
+        return correlate_with_W_shiftsum(W, X)
     k = W.ndim - 2
     A = W.shape[2:]
     Xw = sliding_window_view(_pad_atoms(X, A), A, axis=_shift_axes(k))  # [n, c, *D', *A]
@@ -109,21 +193,25 @@ def _correlate_with_W(W: np.ndarray, X: np.ndarray) -> np.ndarray:
     return contract(W, [m_, c_] + a_, Xw, [n_, c_] + d_ + a_, [n_, m_] + d_)
 
 
-def gradient_H(V: np.ndarray, W: np.ndarray, H: np.ndarray, s: slice = slice(None)):
+def gradient_H(V: np.ndarray, W: np.ndarray, H: np.ndarray, s: slice = slice(None), impl: str = 'contract'):
     """
     neg = correlation of V[s] with W, pos = correlation of R = reconstruct(W, H[s]) with W; both of H[s]'s shape.
     backends/NumPy.py:93-120.
     """
-    neg = _correlate_with_W(W, V[s])
-    pos = _correlate_with_W(W, reconstruct(W, H[s]))
+    neg = _correlate_with_W(W, V[s], impl)
+    pos = _correlate_with_W(W, reconstruct(W, H[s], impl), impl)
     return neg, pos
 
 
-def _correlate_H_with(X: np.ndarray, H: np.ndarray, A: Sequence[int]) -> np.ndarray:
+def _correlate_H_with(X: np.ndarray, H: np.ndarray, A: Sequence[int], impl: str = 'contract') -> np.ndarray:
     """
     out[m,c,a] = sum_n sum_d H[n,m,d+A-1-a] * X[n,c,d]   (contract, then flip the shift axes).
     backends/NumPy.py:77-79,82-85.
     """
+    if impl == 'c':
+        return _c_correlate_H_with(X, H, A)
+    if impl == 'shiftsum':
+        return correlate_H_with_shiftsum(X, H, A)
     k = len(A)
     D = X.shape[2:]
     Hw = sliding_window_view(H, D, axis=_shift_axes(k))          # [n, m, *A, *D]
@@ -134,23 +222,23 @@ def _correlate_H_with(X: np.ndarray, H: np.ndarray, A: Sequence[int]) -> np.ndar
     return np.flip(G, _shift_axes(k))
 
 
-def gradient_W(V: np.ndarray, W: np.ndarray, H: np.ndarray, s: slice = slice(None)):
+def gradient_W(V: np.ndarray, W: np.ndarray, H: np.ndarray, s: slice = slice(None), impl: str = 'contract'):
     """neg from V[s], pos from R = reconstruct(W, H[s]); both of W's shape.  backends/NumPy.py:69-91."""
     A = W.shape[2:]
     Hs = H[s]
-    neg = _correlate_H_with(V[s], Hs, A)
-    pos = _correlate_H_with(reconstruct(W, Hs), Hs, A)
+    neg = _correlate_H_with(V[s], Hs, A, impl)
+    pos = _correlate_H_with(reconstruct(W, Hs, impl), Hs, A, impl)
     return neg, pos
 
 
-def partial_reconstruct(W: np.ndarray, H: np.ndarray, i_atom: int) -> np.ndarray:
+def partial_reconstruct(W: np.ndarray, H: np.ndarray, i_atom: int, impl: str = 'contract') -> np.ndarray:
     """backends/_Backend.py:124-125."""
-    return reconstruct(W[i_atom:i_atom + 1], H[:, i_atom:i_atom + 1])
+    return reconstruct(W[i_atom:i_atom + 1], H[:, i_atom:i_atom + 1], impl)
 
 
-def energy(V: np.ndarray, W: np.ndarray, H: np.ndarray) -> float:
+def energy(V: np.ndarray, W: np.ndarray, H: np.ndarray, impl: str = 'contract') -> float:
     """E = 1/2 sum (V - R)^2.  backends/_Backend.py:127-130."""
-    R = reconstruct(W, H)
+    R = reconstruct(W, H, impl)
     assert R.shape == V.shape
     return float(0.5 * np.sum(np.square(V - R)))
 
@@ -271,7 +359,8 @@ class OracleNMF:
     TransformInvariantNMF.py:142-186 (ctor), :282-348 (fit_batch), :350-442 (fit_minibatches), :506-531.
     """
 
-    def __init__(self, n_atoms: int, atom_shape: Sequence[int], inhibition_range=None):
+    def __init__(self, n_atoms: int, atom_shape: Sequence[int], inhibition_range=None, impl: str = 'contract'):
+        self.impl = impl
         self.n_atoms = n_atoms
         self.atom_shape = tuple(atom_shape)
         k = len(self.atom_shape)
@@ -290,18 +379,18 @@ class OracleNMF:
     # -- properties mirroring the reference's read-outs (TransformInvariantNMF.py:188-215) --
     @property
     def R(self):
-        return reconstruct(self.W, self.H)
+        return reconstruct(self.W, self.H, self.impl)
 
     def R_partial(self, i_atom: int):
-        return partial_reconstruct(self.W, self.H, i_atom)
+        return partial_reconstruct(self.W, self.H, i_atom, self.impl)
 
     def energy(self) -> float:
-        return energy(self.V, self.W, self.H)
+        return energy(self.V, self.W, self.H, self.impl)
 
     # -- half steps --
     def update_H(self, s=slice(None), sparsity=0., inhibition=0., cross_inhibition=0.):
         """TransformInvariantNMF.py:246-271."""
-        neg, pos = gradient_H(self.V, self.W, self.H, s)
+        neg, pos = gradient_H(self.V, self.W, self.H, s, self.impl)
         if inhibition > 0 or cross_inhibition > 0:
             k = len(self.atom_shape)
             g = convolve_multi_1d(self.H[s], self._kernels, range(-k, 0))
@@ -313,12 +402,12 @@ class OracleNMF:
 
     def update_W(self, s=slice(None)):
         """TransformInvariantNMF.py:240-244."""
-        neg, pos = gradient_W(self.V, self.W, self.H, s)
+        neg, pos = gradient_W(self.V, self.W, self.H, s, self.impl)
         multiplicative_update(self.W, neg, pos, self.eps, normalization_axes=self._norm_axes)
 
     def _accumulate(self, acc_neg, acc_pos, lam, s):
         """TransformInvariantNMF.py:444-455 (the += / *= forms, including their in-place side effects)."""
-        neg, pos = gradient_W(self.V, self.W, self.H, s)
+        neg, pos = gradient_W(self.V, self.W, self.H, s, self.impl)
         if lam == 1:
             acc_neg = acc_neg + neg if np.isscalar(acc_neg) else acc_neg.__iadd__(neg)
             acc_pos = acc_pos + pos if np.isscalar(acc_pos) else acc_pos.__iadd__(pos)

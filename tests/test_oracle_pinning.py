@@ -43,6 +43,19 @@ def test_primitives_match_reference_backend(path):
     np.testing.assert_allclose(orc.reconstruct_shiftsum(W, H), g['R'], **tol)
     np.testing.assert_allclose(orc.correlate_with_W_shiftsum(W, V[s]), g['neg_H'], **tol)
     np.testing.assert_allclose(orc.correlate_H_with_shiftsum(V[s], H[s], A), g['neg_W'], **tol)
+    # third: the C flavour (oracle/tnmf_oracle_c.c), in float64 and in float32 (double accumulation)
+    np.testing.assert_allclose(orc.reconstruct(W, H, 'c'), g['R'], **tol)
+    neg, pos = orc.gradient_H(V, W, H, s, 'c')
+    np.testing.assert_allclose(neg, g['neg_H'], **tol)
+    np.testing.assert_allclose(pos, g['pos_H'], **tol)
+    neg, pos = orc.gradient_W(V, W, H, s, 'c')
+    np.testing.assert_allclose(neg, g['neg_W'], **tol)
+    np.testing.assert_allclose(pos, g['pos_W'], **tol)
+    f = np.float32
+    np.testing.assert_allclose(orc.reconstruct(W.astype(f), H.astype(f), 'c'), g['R'], rtol=2e-6)
+    neg, pos = orc.gradient_W(V.astype(f), W.astype(f), H.astype(f), s, 'c')
+    np.testing.assert_allclose(neg, g['neg_W'], rtol=2e-6)
+    np.testing.assert_allclose(pos, g['pos_W'], rtol=5e-6)
 
 
 @pytest.mark.parametrize('path', CASES, ids=[os.path.basename(p)[11:-4] for p in CASES])
@@ -104,7 +117,7 @@ SPARSITY_INHIBITION_ROWS = [
 def test_known_answer_sparsity_inhibition(fit_kw, ctor_kw, E, l1, l0):
     """tnmf/tests/test_sparsity_inhibition.py:58-84: 25 iterations, energy / L1 / L0 of H."""
     np.random.seed(42)
-    nmf = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7), **ctor_kw).fit(racoon_rgb_V(), n_iterations=25, **fit_kw)
+    nmf = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7), impl='c', **ctor_kw).fit(racoon_rgb_V(), n_iterations=25, **fit_kw)
     H = nmf.H
     assert np.isclose(nmf.energy(), E)
     assert np.isclose(np.sum(np.abs(H)), l1)
@@ -127,7 +140,7 @@ def test_known_answer_minibatch(algorithm, E):
     """tnmf/tests/test_minibatch.py:48-76: 768 patches 1x32x32, 10 atoms 7x7, batch 3, 5 epochs, lambda 0.8."""
     V = racoon_patches_V()
     np.random.seed(42)
-    nmf = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7))
+    nmf = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7), impl='c')
     if algorithm == 'full_batch':
         nmf.fit_batch(V, sparsity_H=0.1, n_iterations=5)
     else:
@@ -139,7 +152,17 @@ def test_known_answer_stream():
     """tnmf/tests/test_stream.py:19-25: fit_stream, subsample 50, ASAG-MU -> energy of the LAST subsample 96.7375921."""
     V = racoon_patches_V()
     np.random.seed(42)
-    nmf = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7))
+    nmf = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7), impl='c')
     nmf.fit(V, sparsity_H=0.1, algorithm=orc.MiniBatchAlgorithm.ASAG_MU, subsample_size=50, batch_size=3,
             n_epochs=5, sag_lambda=0.8)
     assert np.isclose(nmf.energy(), 96.7375921)
+
+
+def test_known_answer_stream_limited():
+    """tnmf/tests/test_stream.py:85-108: Cyclic-MU, max_subsamples=5 -> 629.109136."""
+    V = racoon_patches_V()
+    np.random.seed(42)
+    nmf = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7), impl='c')
+    nmf.fit(V, sparsity_H=0.1, algorithm=orc.MiniBatchAlgorithm.Cyclic_MU, subsample_size=50, max_subsamples=5,
+            batch_size=3, n_epochs=5, sag_lambda=0.8)
+    assert np.isclose(nmf.energy(), 629.109136)
