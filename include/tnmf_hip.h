@@ -1,0 +1,125 @@
+/*
+ * tnmf_hip.h -- C ABI of libtnmf_hip.so: the MI355X (gfx950) kernels behind the 'hip' backend of the
+ * shift-invariant multiplicative-update loop of emdgroup/tnmf.
+ *
+ * The reference has no FFI on this path (it is pure Python); the boundary it does have is the Python class
+ * tnmf/backends/_Backend.py:13-130.  Each entry point below names the reference method it stands under.  They are
+ * bound from Python with ctypes (tnmf_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a C-contiguous buffer owned by the caller (e.g. torch.Tensor.data_ptr());
+ *     the library never frees or keeps it beyond the call.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - every function returns int: 0 ok, <0 argument error (TNMF_E_*), >0 a hipError_t.  Nothing throws.
+ *   - element type: geom.dtype 0 = float32, 1 = float64.  'valid' reconstruction mode only:
+ *       V[N,C,*D]  W[M,C,*A]  H[N,M,*(D+A-1)]  R[N,C,*D];   ndim = 1 or 2 shift axes.
+ *   - mini-batch slices are contiguous along the sample axis: the caller offsets V/H/R pointers and passes the slice's N.
+ *   - calls on one ctx are not thread-safe; different ctxs are independent.  All launches are asynchronous on
+ *     `stream` except tnmf_hip_energy, which synchronises the stream to return its scalar.
+ */
+#ifndef TNMF_HIP_H
+#define TNMF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNMF_HIP_ABI_VERSION 1
+
+enum {
+    TNMF_OK = 0,
+    TNMF_E_NULL = -1,      /* required pointer is NULL */
+    TNMF_E_GEOM = -2,      /* bad geometry (ndim, sizes <= 0, atom larger than supported) */
+    TNMF_E_DTYPE = -3,     /* dtype not 0/1 */
+    TNMF_E_WORKSPACE = -4, /* workspace allocation failed */
+    TNMF_E_UNSUPPORTED = -5
+};
+
+typedef struct tnmf_hip_ctx tnmf_hip_ctx;
+
+typedef struct {
+    int ndim;  /* 1 or 2 shift axes */
+    int N;     /* samples in this call (mini-batch slice length) */
+    int M;     /* atoms */
+    int C;     /* channels */
+    int D[2];  /* sample shape; ndim == 1 uses D[0] only */
+    int A[2];  /* atom shape;   ndim == 1 uses A[0] only */
+    int dtype; /* 0 = f32, 1 = f64 */
+} tnmf_hip_geom;
+
+/* Kernel family selection (tnmf_hip_ctx_set_path): AUTO picks the MFMA kernels where the shape allows. */
+enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2 };
+
+int tnmf_hip_abi_version(void);
+const char *tnmf_hip_strerror(int code);
+
+/* One context per device: caches device properties and owns the scratch (R, split-K partials). */
+int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out);
+int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx);
+/* Pre-size the scratch for `geom` so that later calls allocate nothing (graph-capture safe). */
+int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom);
+int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path);
+/* Name of the kernel family the last primitive call on this ctx dispatched to ("generic", "mfma", ...). */
+const char *tnmf_hip_ctx_last_path(const tnmf_hip_ctx *ctx);
+
+/* ---- primitives: API-parity path --------------------------------------------------------------------------- */
+
+/* Backend.reconstruct (tnmf/backends/_Backend.py:120-122; NumPy.py:122-132):
+ *   R[n,c,d] = sum_m sum_a H[n,m,d+a] * W[m,c,A-1-a] */
+int tnmf_hip_reconstruct(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *W, const void *H, void *R,
+                         void *stream);
+
+/* Backend.reconstruction_gradient_H (_Backend.py:110-118; NumPy.py:93-120):
+ *   neg[n,m,u] = sum_c sum_a W[m,c,a] * Vpad[n,c,u+a],  pos = same with R.  R == NULL: R is computed internally. */
+int tnmf_hip_grad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *R_or_null,
+                    const void *W, const void *H, void *neg, void *pos, void *stream);
+
+/* Backend.reconstruction_gradient_W (_Backend.py:100-108; NumPy.py:69-91):
+ *   neg[m,c,a] = sum_n sum_d H[n,m,d+A-1-a] * V[n,c,d],  pos = same with R.  Deterministic two-stage reduction. */
+int tnmf_hip_grad_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *R_or_null,
+                    const void *W, const void *H, void *neg, void *pos, void *stream);
+
+/* TransformInvariantNMF._multiplicative_update (tnmf/TransformInvariantNMF.py:217-235), elementwise part:
+ *   pos += reg (IN PLACE, as the reference does);  arr = (arr * neg) / pos.   dtype 0/1, n_elems elements. */
+int tnmf_hip_mu_update(tnmf_hip_ctx *ctx, int dtype, void *arr, const void *neg, void *pos, double reg,
+                       size_t n_elems, void *stream);
+
+/* Backend.normalize over the atom axes (_Backend.py:75-77 as called from TransformInvariantNMF.py:237-238):
+ *   W[m,c,:] /= sum_a W[m,c,a] */
+int tnmf_hip_normalize_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W, void *stream);
+
+/* Backend.reconstruction_energy (_Backend.py:127-130): *out_host = 1/2 sum (V - R)^2 in double.  Synchronises. */
+int tnmf_hip_energy(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,
+                    double *out_host, void *stream);
+
+/* Backend.convolve_multi_1d (_Backend.py:79-81; _NumPyBackend.py:56-64): zero-padded 'same' convolution of
+ * arr[rows, *shape] along each shift axis with an odd-length kernel (host pointers kernel0/kernel1, doubles). */
+int tnmf_hip_convolve_multi_1d(tnmf_hip_ctx *ctx, int dtype, int ndim, size_t rows, const int *shape,
+                               const void *in, void *out, void *tmp, const double *kernel0, int len0,
+                               const double *kernel1, int len1, void *stream);
+
+/* ---- fused half steps: performance path (same math as the primitives + mu_update) --------------------------- */
+
+/* TransformInvariantNMF._update_H without inhibition (TransformInvariantNMF.py:246-250,271):
+ *   R = reconstruct(W,H);  H *= corr(W,V) / (corr(W,R) + eps + sparsity), in place.
+ *   R_scratch: device buffer [N,C,*D] or NULL (ctx scratch is used).  r_is_valid != 0: R_scratch already holds
+ *   reconstruct(W, H) (the caller ran tnmf_hip_reconstruct itself, e.g. to time the two kernels separately). */
+int tnmf_hip_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, void *H_inout,
+                      void *R_scratch, int r_is_valid, double eps, double sparsity, void *stream);
+
+/* Local part of TransformInvariantNMF._update_W (TransformInvariantNMF.py:240-241 / :444-448):
+ *   negpos[0] = neg_W, negpos[1] = pos_W as one contiguous [2,M,C,*A] buffer (what the all-reduce carries).
+ *   R_scratch / r_is_valid as for tnmf_hip_update_H. */
+int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,
+                          void *R_scratch, int r_is_valid, void *negpos, void *stream);
+
+/* Rest of _update_W (TransformInvariantNMF.py:232-238,244): W = W * neg / (pos + eps); W /= sum over atom axes.
+ * `pos` is left incremented by eps, like the reference's in-place `pos += eps`. */
+int tnmf_hip_apply_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W_inout, void *negpos, double eps,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNMF_HIP_H */

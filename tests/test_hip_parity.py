@@ -1,0 +1,237 @@
+"""
+GPU parity tests proper: the 'hip' backend (hand-written gfx950 kernels behind the C ABI) against
+  * the golden vectors of the genuine reference PyTorch backend (tests/golden/primitives_*.npz),
+  * the pinned CPU oracle on seeded inputs (edge shapes, ragged tiles, empty slices),
+  * the reference's own known-answer energies, run end to end through backend='hip' in float64.
+Tolerances: float64 1e-10 relative; float32 per-primitive 2e-5 of the output's max (K up to ~5e3 f32 FMAs),
+W after a fixed 5 iterations 1e-5 (north star), energy gap 1e-5.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import tnmf_oracle as orc
+from test_oracle_pinning import V_1D, racoon_patches_V, racoon_rgb_V
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tnmf_amd.backends.HIP import HIP_Backend
+    from tnmf_amd.TransformInvariantNMF import MiniBatchAlgorithm, TransformInvariantNMF
+
+CASES = sorted(glob.glob(os.path.join(GOLDEN, 'primitives_*.npz')))
+PATHS = ['generic', 'auto']
+
+
+def dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+def relmax(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    scale = np.abs(want).max()
+    return np.abs(np.asarray(got, dtype=np.float64) - want).max() / (scale if scale > 0 else 1.0)
+
+
+def make_backend(V, A, M, path):
+    be = HIP_Backend(path=path)
+    k = len(A)
+    np.random.seed(1)
+    be.initialize(V, tuple(A), M, None, tuple(range(-k, 0)))
+    return be
+
+
+def _slice(g):
+    lo, hi = g['slice']
+    return slice(None) if lo < 0 else slice(int(lo), int(hi))
+
+
+@pytest.mark.parametrize('path', PATHS)
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-10), (np.float32, 2e-5)], ids=['f64', 'f32'])
+@pytest.mark.parametrize('case', CASES, ids=[os.path.basename(p)[11:-4] for p in CASES])
+def test_primitives_against_reference_golden(case, dtype, tol, path):
+    g = np.load(case)
+    V, s = g['V'].astype(dtype), _slice(g)
+    A, M = g['W'].shape[2:], g['W'].shape[0]
+    k = len(A)
+    be = make_backend(V, A, M, path)
+    W, H = dev(g['W'], dtype), dev(g['H'], dtype)
+    assert relmax(be.to_ndarray(be.reconstruct(W, H)), g['R']) < tol
+    neg, pos = be.reconstruction_gradient_H(V, W, H, s)
+    assert neg.shape == H[s].shape
+    assert relmax(be.to_ndarray(neg), g['neg_H']) < tol
+    assert relmax(be.to_ndarray(pos), g['pos_H']) < tol
+    neg, pos = be.reconstruction_gradient_W(V, W, H, s)
+    assert neg.shape == W.shape
+    assert relmax(be.to_ndarray(neg), g['neg_W']) < tol
+    assert relmax(be.to_ndarray(pos), g['pos_W']) < tol
+    assert abs(be.reconstruction_energy(V, W, H) - float(g['energy'])) / float(g['energy']) < tol
+    assert relmax(be.to_ndarray(be.partial_reconstruct(W, H, M - 1)), g['R_partial_last']) < tol
+    kern = orc.inhibition_kernels(tuple(a - 1 for a in A))
+    assert relmax(be.to_ndarray(be.convolve_multi_1d(H, kern, tuple(range(-k, 0)))), g['inhibition_conv']) < tol
+    assert be.last_path in ('generic', 'mfma')
+
+
+@pytest.mark.parametrize('case', CASES[:3], ids=[os.path.basename(p)[11:-4] for p in CASES[:3]])
+def test_seeded_init_matches_reference(case):
+    g = np.load(case)
+    V, A, M = g['V'], g['W'].shape[2:], g['W'].shape[0]
+    be = HIP_Backend()
+    np.random.seed(42)
+    W, H = be.initialize(V, tuple(A), M, None, tuple(range(-len(A), 0)))
+    assert np.array_equal(be.to_ndarray(H), g['init_H_seed42'])
+    np.testing.assert_allclose(be.to_ndarray(W), g['init_W_seed42'], rtol=1e-14)
+
+
+SHAPES = [
+    # N, C, D, M, A          (ragged tiles, M not a multiple of 32, wide atoms, long 1-D signals, single sample)
+    (3, 1, (37, 45), 16, (9, 9)),
+    (2, 3, (33, 31), 7, (5, 8)),
+    (1, 1, (64, 64), 32, (12, 12)),
+    (2, 2, (20, 70), 33, (16, 16)),
+    (2, 1, (1000,), 8, (20,)),
+    (5, 3, (257,), 3, (1,)),
+    (2, 1, (5, 6), 2, (5, 6)),
+]
+
+
+@pytest.mark.parametrize('path', PATHS)
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-10), (np.float32, 2e-5)], ids=['f64', 'f32'])
+@pytest.mark.parametrize('shape', SHAPES, ids=[f'{s[0]}x{s[1]}x{"x".join(map(str, s[2]))}_m{s[3]}_a{"x".join(map(str, s[4]))}' for s in SHAPES])
+def test_primitives_against_oracle(shape, dtype, tol, path):
+    N, C, D, M, A = shape
+    k = len(A)
+    rng = np.random.default_rng(N * 1000 + M)
+    V = rng.random((N, C) + D)
+    Wn = rng.random((M, C) + A)
+    Wn /= Wn.sum(axis=tuple(range(-k, 0)), keepdims=True)
+    Hn = rng.random((N, M) + tuple(d + a - 1 for d, a in zip(D, A)))
+    be = make_backend(V.astype(dtype), A, M, path)
+    W, H = dev(Wn, dtype), dev(Hn, dtype)
+    assert relmax(be.to_ndarray(be.reconstruct(W, H)), orc.reconstruct(Wn, Hn, 'c')) < tol
+    for s in (slice(None), slice(0, 0), slice(N - 1, N)):
+        on, op = orc.gradient_H(V, Wn, Hn, s, 'c')
+        neg, pos = be.reconstruction_gradient_H(V, W, H, s)
+        assert tuple(neg.shape) == on.shape
+        if on.size:
+            assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+        on, op = orc.gradient_W(V, Wn, Hn, s, 'c')
+        neg, pos = be.reconstruction_gradient_W(V, W, H, s)
+        assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+    # elementwise MU incl. the reference's in-place `pos += reg` side effect
+    arr, neg, pos = dev(Hn, dtype), dev(rng.random(Hn.shape), dtype), dev(rng.random(Hn.shape), dtype)
+    want_pos = be.to_ndarray(pos).copy() + dtype(0.25)
+    want = (be.to_ndarray(arr) * be.to_ndarray(neg)) / want_pos
+    be.multiplicative_update(arr, neg, pos, 0.25)
+    assert np.array_equal(be.to_ndarray(pos), want_pos)
+    np.testing.assert_allclose(be.to_ndarray(arr), want, rtol=1e-6 if dtype == np.float32 else 1e-14)
+    # fused half steps == primitives + MU
+    Hf = dev(Hn, dtype)
+    be.fused_update_H(V, W, Hf, slice(None), sparsity=0.1, eps=1e-9)
+    on, op = orc.gradient_H(V, Wn, Hn, slice(None), 'c')
+    assert relmax(be.to_ndarray(Hf), Hn * on / (op + 1e-9 + 0.1)) < 2 * tol
+    Wf = dev(Wn, dtype)
+    be.fused_update_W(V, Wf, H, slice(None), eps=1e-9)
+    on, op = orc.gradient_W(V, Wn, Hn, slice(None), 'c')
+    Wo = Wn * on / (op + 1e-9)
+    Wo /= Wo.sum(axis=tuple(range(-k, 0)), keepdims=True)
+    assert relmax(be.to_ndarray(Wf), Wo) < 2 * tol
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# end to end through backend='hip'
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'unfused'])
+def test_known_answer_1d_inhibition_f64(fused):
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=3, atom_shape=(5,), backend='hip', use_fused_updates=fused)
+    nmf.fit(V_1D, inhibition_strength=0.1, n_iterations=10)
+    assert np.isclose(nmf._energy_function(), 2.34946)            # tnmf/tests/test_1d.py:18
+    assert np.allclose(nmf.W.sum(axis=-1), 1.)
+
+
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'unfused'])
+def test_known_answer_2d_rgb_f64(fused):
+    V = racoon_rgb_V()
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=10, atom_shape=(7, 7), backend='hip', use_fused_updates=fused)
+    nmf.fit(V, sparsity_H=0.1, n_iterations=10)
+    assert np.isclose(nmf._energy_function(), 268.14423)          # tnmf/tests/test_backends.py:18
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7), impl='c').fit(V, sparsity_H=0.1, n_iterations=10)
+    assert np.allclose(nmf.W, ref.W) and np.allclose(nmf.H, ref.H)  # the reference's own acceptance criterion
+    assert np.allclose(nmf.R, ref.R) and np.allclose(nmf.R_partial(0), ref.R_partial(0))
+    assert np.allclose(nmf.W.sum(axis=(-1, -2)), 1.)
+
+
+@pytest.mark.parametrize('fit_kw,ctor_kw,E,l1,l0', [
+    # tnmf/tests/test_sparsity_inhibition.py:20-52 (subset)
+    (dict(sparsity_H=1.0), dict(), 2429.69334, 2114.50047, 136396),
+    (dict(inhibition_strength=1.0), dict(inhibition_range=(3, 3)), 1119.00855, 4657.19574, 168777),
+    (dict(cross_atom_inhibition_strength=0.5), dict(inhibition_range=(3, 3)), 724.238350, 4953.89250, 175219),
+])
+def test_known_answer_sparsity_inhibition_f64(fit_kw, ctor_kw, E, l1, l0):
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=10, atom_shape=(7, 7), backend='hip', **ctor_kw)
+    nmf.fit(racoon_rgb_V(), n_iterations=25, **fit_kw)
+    H = nmf.H
+    assert np.isclose(nmf._energy_function(), E)
+    assert np.isclose(np.sum(np.abs(H)), l1)
+    assert np.isclose(np.sum(H / H.max() > 1e-7), l0)
+
+
+@pytest.mark.parametrize('algorithm,E', [
+    # tnmf/tests/test_minibatch.py:18-25
+    ('full_batch', 14434.02658), ('Cyclic_MU', 14434.02658), ('ASG_MU', 4558.86695), ('GSG_MU', 14223.14454),
+    ('ASAG_MU', 4560.03432), ('GSAG_MU', 14310.92041),
+])
+def test_known_answer_minibatch_f64(algorithm, E):
+    V = racoon_patches_V()
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=10, atom_shape=(7, 7), backend='hip')
+    if algorithm == 'full_batch':
+        nmf.fit_batch(V, sparsity_H=0.1, n_iterations=5)
+    else:
+        nmf.fit_minibatches(V, sparsity_H=0.1, algorithm=MiniBatchAlgorithm[algorithm], batch_size=3, n_epochs=5,
+                            sag_lambda=0.8)
+    assert np.isclose(nmf._energy_function(), E)
+
+
+def test_known_answer_stream_f64():
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=10, atom_shape=(7, 7), backend='hip')
+    nmf.fit((v for v in racoon_patches_V()), sparsity_H=0.1, algorithm=MiniBatchAlgorithm.ASAG_MU, subsample_size=50,
+            batch_size=3, n_epochs=5, sag_lambda=0.8)
+    assert np.isclose(nmf._energy_function(), 96.7375921)         # tnmf/tests/test_stream.py:25
+
+
+@pytest.mark.parametrize('path', PATHS)
+@pytest.mark.parametrize('N,C,D,M,A', [(8, 1, (64, 64), 8, (9, 9)), (4, 1, (96, 80), 32, (12, 12)), (3, 3, (48, 48), 32, (12, 12))])
+def test_f32_loop_parity_with_f64_oracle(N, C, D, M, A, path):
+    """North-star criterion: W within 1e-5 (max-relative) of the float64 reference after a fixed 5 iterations."""
+    rng = np.random.default_rng(11)
+    Wt = rng.random((M, C) + A)
+    Ht = rng.random((N, M) + tuple(d + a - 1 for d, a in zip(D, A))) * (rng.random((N, M) + tuple(d + a - 1 for d, a in zip(D, A))) < 0.01)
+    V = (orc.reconstruct(Wt, Ht, 'c') + 0.01 * rng.random((N, C) + D)).astype(np.float32)
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=M, atom_shape=A, backend='hip', path=path)
+    nmf.fit(V, n_iterations=5, progress_callback=lambda *_: True)
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c').fit(V.astype(np.float64), n_iterations=5)
+    assert relmax(nmf.W, ref.W) < 1e-5
+    assert relmax(nmf.H, ref.H) < 1e-4
+    assert abs(nmf._energy_function() - ref.energy()) / ref.energy() < 1e-5
+
+
+def test_errors_like_the_reference():
+    with pytest.raises(NotImplementedError):
+        HIP_Backend(reconstruction_mode='full')                   # NumPy.py:26-27 precedent
+    be = HIP_Backend()
+    with pytest.raises(TypeError):
+        be.initialize(np.ones((1, 1, 8), dtype=np.int32), (3,), 2, None, (-1,))
+    with pytest.raises(NotImplementedError):
+        be.initialize(np.ones((1, 1, 4, 4, 4)), (2, 2, 2), 2, None, (-3, -2, -1))

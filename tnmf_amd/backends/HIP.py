@@ -1,0 +1,366 @@
+"""
+The 'hip' backend: every primitive of the shift-invariant MU loop runs as a hand-written gfx950 kernel of
+libtnmf_hip.so (C ABI: include/tnmf_hip.h), called through ctypes on raw device pointers.
+
+PyTorch is plumbing here: it owns the device buffers (``torch.Tensor``), the current HIP stream and -- for the
+sample-sharded multi-GPU mode -- the RCCL all-reduce (``torch.distributed``).  No arithmetic of the hot path is
+done by torch, and there is no CPU fallback: without the built library or without a GPU the constructor raises.
+
+Reference counterparts: tnmf/backends/NumPy.py (the 'valid'-mode direct-convolution backend whose results this
+backend reproduces) and tnmf/backends/_Backend.py (the interface).
+"""
+from typing import Optional, Sequence, Tuple
+
+import ctypes
+import numpy as np
+import torch
+
+from .. import _lib, sharding
+from ._Backend import Backend, sliceNone
+
+_DTYPES = {np.dtype('float32'): (torch.float32, 0), np.dtype('float64'): (torch.float64, 1)}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class _EventSpan:
+    """Brackets a launch with two HIP events on the current stream when the backend's timeline is on."""
+
+    def __init__(self, backend, name):
+        self.backend, self.name = backend, name
+
+    def __enter__(self):
+        if self.backend._timeline is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.backend._device))
+        return self
+
+    def __exit__(self, *exc):
+        if self.backend._timeline is not None:
+            self.e1.record(torch.cuda.current_stream(self.backend._device))
+            self.backend._timeline.append((self.name, self.e0, self.e1))
+        return False
+
+
+class HIP_Backend(Backend):
+    r"""
+    MI355X backend for 'valid'-mode shift-invariant NMF (1-D and 2-D shifts, float32 and float64).
+
+    Parameters
+    ----------
+    reconstruction_mode : only ``'valid'`` (like the reference NumPy backend, NumPy.py:26-27)
+    device : CUDA/HIP device index or ``torch.device``; default: the current device
+    path : ``'auto'`` | ``'generic'`` | ``'mfma'`` -- kernel family (``'auto'`` = MFMA where the shape allows)
+    init : ``'reference'`` draws H then W from the global legacy NumPy RNG exactly like the reference
+           (_Backend.py:92-95); ``'device'`` draws them with the device generator (fast, not seed-compatible)
+    process_group : a ``torch.distributed`` group, ``True`` for the default group, or ``None``.  With a group the
+           sample axis is sharded in contiguous blocks over the ranks: this rank keeps V[n0:n1] and H[n0:n1], the
+           W-gradient numerator/denominator is all-reduced (sum) before it is returned, the energy likewise.
+    """
+
+    def __init__(self, reconstruction_mode: str = 'valid', device=None, path: str = 'auto', init: str = 'reference',
+                 process_group=None):
+        if reconstruction_mode != 'valid':
+            raise NotImplementedError('The hip backend only supports the "valid" reconstruction mode.')
+        super().__init__(reconstruction_mode=reconstruction_mode)
+        self._lib = _lib.load()  # raises when the extension is not built
+        if not torch.cuda.is_available():
+            raise RuntimeError('The hip backend needs a GPU (torch.cuda.is_available() is False); there is no CPU path.')
+        if init not in ('reference', 'device'):
+            raise ValueError(f'init must be "reference" or "device", not {init!r}')
+        self._device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if self._device.index is None:
+            self._device = torch.device('cuda', torch.cuda.current_device())
+        self._init_mode = init
+        self._ctx = ctypes.c_void_p()
+        _lib.check(self._lib.tnmf_hip_ctx_create(self._device.index, ctypes.byref(self._ctx)), 'tnmf_hip_ctx_create')
+        _lib.check(self._lib.tnmf_hip_ctx_set_path(self._ctx, _lib.PATHS[path]), 'tnmf_hip_ctx_set_path')
+
+        self._group = None
+        self._rank, self._world = 0, 1
+        if process_group is not None and process_group is not False:
+            import torch.distributed as dist
+            self._group = dist.group.WORLD if process_group is True else process_group
+            self._rank, self._world = dist.get_rank(self._group), dist.get_world_size(self._group)
+
+        self._torch_dtype = None
+        self._dtype_code = None
+        self._V_dev = None          # this rank's samples, device resident
+        self._shard = (0, 0)        # [n0, n1) of the global sample axis held by this rank
+        self._R_scratch = None
+        self._negpos = None
+        self._timeline = None
+
+    def __del__(self):
+        try:
+            if getattr(self, '_ctx', None) is not None and self._ctx.value:
+                self._lib.tnmf_hip_ctx_destroy(self._ctx)
+                self._ctx = ctypes.c_void_p()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    # -- helpers --------------------------------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    @property
+    def shard(self) -> Tuple[int, int]:
+        """Global sample range [n0, n1) resident on this rank."""
+        return self._shard
+
+    @property
+    def last_path(self) -> str:
+        return self._lib.tnmf_hip_ctx_last_path(self._ctx).decode()
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    # -- optional per-kernel timeline (bench.py): HIP events on the stream the kernels are launched on ----------
+    def start_timeline(self) -> None:
+        """From now on the fused half steps launch their reconstruct separately and bracket every kernel group with
+        HIP events (recorded on the launch stream, no host synchronisation)."""
+        self._timeline = []
+
+    def stop_timeline(self):
+        """-> {name: [milliseconds per launch, ...]}; synchronises."""
+        torch.cuda.synchronize(self._device)
+        out = {}
+        for name, e0, e1 in self._timeline or []:
+            out.setdefault(name, []).append(e0.elapsed_time(e1))
+        self._timeline = None
+        return out
+
+    def _timed(self, name: str):
+        return _EventSpan(self, name)
+
+    def _geom(self, n: int, n_atoms: int):
+        return _lib.make_geom(n, n_atoms, self.n_channels, self._sample_shape, self.atom_shape, self._dtype_code)
+
+    def _check_W(self, W: torch.Tensor):
+        assert W.is_cuda and W.is_contiguous() and W.dtype == self._torch_dtype
+        assert tuple(W.shape[1:]) == (self.n_channels,) + self.atom_shape
+
+    def _check_H(self, H: torch.Tensor, n_atoms: int):
+        assert H.is_cuda and H.is_contiguous() and H.dtype == self._torch_dtype
+        assert tuple(H.shape[1:]) == (n_atoms,) + self._transform_shape
+
+    def _local(self, s: slice) -> slice:
+        """Slices address this rank's resident samples (all samples when there is no process group)."""
+        lo, hi, step = s.indices(self._shard[1] - self._shard[0])
+        assert step == 1, 'sample slices must be contiguous'
+        return slice(lo, max(lo, hi))
+
+    @property
+    def n_local_samples(self) -> int:
+        return self._shard[1] - self._shard[0]
+
+    def minibatch_slices(self, batch_size: Optional[int]):
+        """
+        Sequential mini-batches in this rank's sample coordinates.  With a process group, global batch j is the
+        union of every rank's local batch j: each rank contributes ceil(batch_size / world) of its own samples,
+        and all ranks get the same number of batches (possibly empty at the tail) so their all-reduces pair up.
+        Without a group this is the reference's sequential split (TransformInvariantNMF.py:29-37).
+        """
+        return sharding.local_minibatches(self.n_samples, self._rank, self._world, batch_size)
+
+    def _all_reduce(self, t: torch.Tensor) -> None:
+        sharding.all_reduce_sum(t, self._group)
+
+    # -- set-up ---------------------------------------------------------------------------------------------
+    def _initialize_matrices(self, V: np.ndarray, atom_shape, n_atoms: int, W=None, axes_W_normalization=None):
+        if V.dtype not in _DTYPES:
+            raise TypeError(f'the hip backend computes in float32 or float64, V has dtype {V.dtype}')
+        if len(atom_shape) not in (1, 2):
+            raise NotImplementedError('the hip backend supports 1 or 2 shift dimensions')
+        self._torch_dtype, self._dtype_code = _DTYPES[V.dtype]
+        N = self.n_samples
+        n0, n1 = self._shard = sharding.shard_bounds(N, self._rank, self._world)
+        with torch.cuda.device(self._device):
+            self._V_dev = torch.as_tensor(np.ascontiguousarray(V[n0:n1])).to(self._device)
+            H = torch.empty((n1 - n0, n_atoms) + self._transform_shape, dtype=self._torch_dtype, device=self._device)
+            if self._init_mode == 'device':
+                H.uniform_(0, 1).neg_().add_(1)
+            else:
+                for i, h in sharding.reference_init_stream(N, (n_atoms,) + self._transform_shape, self._shard, V.dtype):
+                    H[i].copy_(torch.from_numpy(h))
+            if W is None:
+                if self._init_mode == 'device' and self._world == 1:
+                    W = torch.empty((n_atoms, self.n_channels) + self.atom_shape, dtype=self._torch_dtype,
+                                    device=self._device).uniform_(0, 1).neg_().add_(1)
+                    self.normalize(W, axes_W_normalization)
+                else:
+                    W = torch.from_numpy(sharding.reference_init_W(n_atoms, self.n_channels, self.atom_shape,
+                                                                   V.dtype)).to(self._device)
+            else:
+                self._check_W(W)
+            self._R_scratch = torch.empty_like(self._V_dev)
+            self._negpos = torch.empty((2, n_atoms, self.n_channels) + self.atom_shape, dtype=self._torch_dtype,
+                                       device=self._device)
+            _lib.check(self._lib.tnmf_hip_ctx_reserve(self._ctx, ctypes.byref(self._geom(n1 - n0, n_atoms))),
+                       'tnmf_hip_ctx_reserve')
+        return W, H
+
+    # -- primitives -----------------------------------------------------------------------------------------
+    def reconstruct(self, W: torch.Tensor, H: torch.Tensor) -> torch.Tensor:
+        """R = H (*) W, 'valid' part (reference: NumPy.py:122-132) -> tnmf_hip_reconstruct."""
+        self._check_W(W)
+        if not H.is_contiguous():
+            H = H.contiguous()
+        self._check_H(H, W.shape[0])
+        R = torch.empty((H.shape[0], self.n_channels) + self._sample_shape, dtype=self._torch_dtype, device=self._device)
+        g = self._geom(H.shape[0], W.shape[0])
+        _lib.check(self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(H), _ptr(R),
+                                                  self._stream()), 'tnmf_hip_reconstruct')
+        return R
+
+    def reconstruction_gradient_H(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone):
+        """(neg, pos) of H[s]'s shape (reference: NumPy.py:93-120) -> tnmf_hip_grad_H.  `V` is the array given to
+        initialize(); the device-resident copy is used (precedent: NumPy_CachingFFT.py:259,273)."""
+        self._check_W(W)
+        ls = self._local(s)
+        Hs, Vs = H[ls], self._V_dev[ls]
+        self._check_H(Hs, W.shape[0])
+        neg, pos = torch.empty_like(Hs), torch.empty_like(Hs)
+        g = self._geom(Hs.shape[0], W.shape[0])
+        _lib.check(self._lib.tnmf_hip_grad_H(self._ctx, ctypes.byref(g), _ptr(Vs), None, _ptr(W), _ptr(Hs),
+                                             _ptr(neg), _ptr(pos), self._stream()), 'tnmf_hip_grad_H')
+        return neg, pos
+
+    def _local_grad_W(self, W, H, s) -> torch.Tensor:
+        ls = self._local(s)
+        Hs, Vs = H[ls], self._V_dev[ls]
+        self._check_W(W)
+        self._check_H(Hs, W.shape[0])
+        negpos = torch.empty_like(self._negpos)
+        g = self._geom(Hs.shape[0], W.shape[0])
+        Rs = self._R_scratch[ls] if Hs.shape[0] else None
+        r_valid = 0
+        if self._timeline is not None and Hs.shape[0]:
+            with self._timed('reconstruct'):
+                _lib.check(self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(Hs), _ptr(Rs),
+                                                          self._stream()), 'tnmf_hip_reconstruct')
+            r_valid = 1
+        with self._timed('grad_W'):
+            _lib.check(self._lib.tnmf_hip_grad_W_fused(self._ctx, ctypes.byref(g), _ptr(Vs), _ptr(W), _ptr(Hs),
+                                                       _ptr(Rs), r_valid, _ptr(negpos), self._stream()),
+                       'tnmf_hip_grad_W_fused')
+        return negpos
+
+    def reconstruction_gradient_W(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone):
+        """(neg, pos) of W's shape (reference: NumPy.py:69-91) -> tnmf_hip_grad_W_fused; summed over the ranks of
+        the process group (one all-reduce of the contiguous [neg | pos] buffer)."""
+        negpos = self._local_grad_W(W, H, s)
+        self._all_reduce(negpos)
+        return negpos[0], negpos[1]
+
+    def reconstruction_energy(self, V, W: torch.Tensor, H: torch.Tensor) -> float:
+        """1/2 sum (V - R)^2 (reference: _Backend.py:127-130) -> tnmf_hip_energy (+ all-reduce)."""
+        self._check_W(W)
+        self._check_H(H, W.shape[0])
+        out = ctypes.c_double(0.0)
+        g = self._geom(H.shape[0], W.shape[0])
+        _lib.check(self._lib.tnmf_hip_energy(self._ctx, ctypes.byref(g), _ptr(self._V_dev), _ptr(W), _ptr(H),
+                                             ctypes.byref(out), self._stream()), 'tnmf_hip_energy')
+        if self._world > 1:
+            t = torch.tensor([out.value], dtype=torch.float64, device=self._device)
+            self._all_reduce(t)
+            return float(t.item())
+        return float(out.value)
+
+    def partial_reconstruct(self, W, H, i_atom: int):
+        return self.reconstruct(W[i_atom:i_atom + 1].contiguous(), H[:, i_atom:i_atom + 1].contiguous())
+
+    def normalize(self, arr: torch.Tensor, axis=None) -> None:
+        """arr /= arr.sum(axis, keepdims=True) for W over its atom axes (reference: _Backend.py:75-77)."""
+        k = len(self.atom_shape)
+        ax = tuple(sorted(a % arr.ndim for a in ((axis,) if isinstance(axis, int) else tuple(axis or ()))))
+        if ax != tuple(range(arr.ndim - k, arr.ndim)) or tuple(arr.shape[-k:]) != self.atom_shape:
+            raise NotImplementedError('the hip backend normalises dictionaries over their atom axes only')
+        assert arr.is_cuda and arr.is_contiguous()
+        rows = int(np.prod(arr.shape[:-k]))
+        g = _lib.make_geom(0, rows, 1, self._sample_shape, self.atom_shape, self._dtype_code)
+        _lib.check(self._lib.tnmf_hip_normalize_W(self._ctx, ctypes.byref(g), _ptr(arr), self._stream()),
+                   'tnmf_hip_normalize_W')
+
+    def convolve_multi_1d(self, arr: torch.Tensor, kernels: Sequence[np.ndarray], axes: Sequence[int]) -> torch.Tensor:
+        """Separable zero-padded convolution along the shift axes (reference: _NumPyBackend.py:56-64)."""
+        k = len(self.atom_shape)
+        axes = tuple(a % arr.ndim for a in axes)
+        if axes != tuple(range(arr.ndim - k, arr.ndim)) or len(kernels) != k:
+            raise NotImplementedError('the hip backend convolves along the shift axes only')
+        assert arr.is_cuda and arr.is_contiguous()
+        out = torch.empty_like(arr)
+        tmp = torch.empty_like(arr) if k == 2 else None
+        ks = [np.ascontiguousarray(kk, dtype=np.float64) for kk in kernels]
+        kp = [kk.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for kk in ks]
+        shape = (ctypes.c_int * 2)(*[int(x) for x in arr.shape[-k:]] + [1] * (2 - k))
+        rows = int(np.prod(arr.shape[:-k]))
+        _lib.check(self._lib.tnmf_hip_convolve_multi_1d(
+            self._ctx, self._dtype_code, k, rows, shape, _ptr(arr), _ptr(out), _ptr(tmp), kp[0], len(ks[0]),
+            kp[1] if k == 2 else None, len(ks[1]) if k == 2 else 0, self._stream()), 'tnmf_hip_convolve_multi_1d')
+        return out
+
+    @staticmethod
+    def to_ndarray(arr: torch.Tensor) -> np.ndarray:
+        """Device tensor -> host ndarray (with a process group: this rank's shard of H / R)."""
+        return arr.detach().cpu().numpy()
+
+    # -- optional hooks used by the front-end ---------------------------------------------------------------
+    def multiplicative_update(self, arr: torch.Tensor, neg: torch.Tensor, pos: torch.Tensor, regularization: float):
+        """pos += reg (in place); arr = arr * neg / pos  (reference: TransformInvariantNMF.py:232-235)."""
+        assert arr.is_contiguous() and neg.is_contiguous() and pos.is_contiguous()
+        assert arr.shape == neg.shape == pos.shape
+        _lib.check(self._lib.tnmf_hip_mu_update(self._ctx, self._dtype_code, _ptr(arr), _ptr(neg), _ptr(pos),
+                                                float(regularization), arr.numel(), self._stream()),
+                   'tnmf_hip_mu_update')
+
+    def fused_update_H(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone, sparsity: float = 0.,
+                       eps: float = 1e-9) -> None:
+        """One H half step without inhibition, in place (reference: TransformInvariantNMF.py:246-250,271)."""
+        ls = self._local(s)
+        Hs, Vs = H[ls], self._V_dev[ls]
+        if Hs.shape[0] == 0:
+            return
+        self._check_W(W)
+        self._check_H(Hs, W.shape[0])
+        g = self._geom(Hs.shape[0], W.shape[0])
+        Rs = self._R_scratch[ls]
+        r_valid = 0
+        if self._timeline is not None:
+            with self._timed('reconstruct'):
+                _lib.check(self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(Hs), _ptr(Rs),
+                                                          self._stream()), 'tnmf_hip_reconstruct')
+            r_valid = 1
+        with self._timed('update_H'):
+            _lib.check(self._lib.tnmf_hip_update_H(self._ctx, ctypes.byref(g), _ptr(Vs), _ptr(W), _ptr(Hs), _ptr(Rs),
+                                                   r_valid, float(eps), float(sparsity), self._stream()),
+                       'tnmf_hip_update_H')
+
+    def apply_W(self, W: torch.Tensor, negpos: torch.Tensor, eps: float = 1e-9) -> None:
+        """W = W * neg / (pos + eps), then normalise over the atom axes (TransformInvariantNMF.py:232-238)."""
+        self._check_W(W)
+        assert negpos.is_contiguous() and tuple(negpos.shape) == (2,) + tuple(W.shape)
+        g = self._geom(0, W.shape[0])
+        with self._timed('apply_W'):
+            _lib.check(self._lib.tnmf_hip_apply_W(self._ctx, ctypes.byref(g), _ptr(W), _ptr(negpos), float(eps),
+                                                  self._stream()), 'tnmf_hip_apply_W')
+
+    def local_gradient_W(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone) -> torch.Tensor:
+        """This rank's [neg | pos] of the W gradient as one [2, M, C, *A] buffer, NOT yet summed over ranks."""
+        return self._local_grad_W(W, H, s)
+
+    def all_reduce_gradient_W(self, negpos: torch.Tensor) -> torch.Tensor:
+        """Sum a [neg | pos] buffer over the ranks of the process group (one RCCL all-reduce over xGMI)."""
+        self._all_reduce(negpos)
+        return negpos
+
+    def fused_update_W(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone, eps: float = 1e-9) -> None:
+        """One W half step, in place: local gradient, all-reduce over the ranks, MU + normalise
+        (reference: TransformInvariantNMF.py:240-244)."""
+        negpos = self._local_grad_W(W, H, s)
+        self._all_reduce(negpos)
+        self.apply_W(W, negpos, eps)

@@ -1,0 +1,350 @@
+// api.hip -- the extern "C" surface of libtnmf_hip.so (include/tnmf_hip.h): argument checks, scratch management and
+// dispatch between the kernel families.  No torch types, no exceptions, no allocation inside a call once
+// tnmf_hip_ctx_reserve() has sized the scratch.
+#include <new>
+
+#include "generic.h"
+#include "mfma.h"
+
+namespace {
+
+int to_geo(const tnmf_hip_geom *in, Geo *g) {
+    if (!in) return TNMF_E_NULL;
+    if (in->dtype != 0 && in->dtype != 1) return TNMF_E_DTYPE;
+    if (in->ndim != 1 && in->ndim != 2) return TNMF_E_GEOM;
+    g->N = in->N;
+    g->M = in->M;
+    g->C = in->C;
+    if (in->ndim == 1) {
+        g->Dy = 1;
+        g->Dx = in->D[0];
+        g->Ay = 1;
+        g->Ax = in->A[0];
+    } else {
+        g->Dy = in->D[0];
+        g->Dx = in->D[1];
+        g->Ay = in->A[0];
+        g->Ax = in->A[1];
+    }
+    if (g->N < 0 || g->M <= 0 || g->C <= 0 || g->Dy <= 0 || g->Dx <= 0 || g->Ay <= 0 || g->Ax <= 0)
+        return TNMF_E_GEOM;
+    g->Hy = g->Dy + g->Ay - 1;
+    g->Hx = g->Dx + g->Ax - 1;
+    return TNMF_OK;
+}
+
+inline size_t esize(int dtype) { return dtype == 0 ? 4 : 8; }
+
+// scratch layout: [R (N*C*D elements)] [split-K partials (doubles)] [energy partials + result (doubles)]
+struct Scratch {
+    size_t r_off, r_bytes;
+    size_t part_off, part_bytes;
+    size_t red_off, red_bytes;
+    size_t total;
+    int P;
+};
+
+Scratch plan_scratch(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
+    Scratch s;
+    s.r_off = 0;
+    s.r_bytes = align_up((size_t)g.N * g.C * g.Dy * g.Dx * esize(dtype), 256);
+    int P = generic_corr_H_chunks(ctx, g);
+    const int Pm = mfma_corr_H_chunks(ctx, g);
+    if (Pm > P) P = Pm;
+    s.P = P;
+    s.part_off = s.r_off + s.r_bytes;
+    s.part_bytes = align_up((size_t)P * g.M * g.C * g.Ay * g.Ax * 2 * sizeof(double), 256);
+    s.red_off = s.part_off + s.part_bytes;
+    s.red_bytes = align_up((size_t)(kEnergyPartials + 8) * sizeof(double), 256);
+    s.total = s.red_off + s.red_bytes;
+    return s;
+}
+
+int ensure_scratch(tnmf_hip_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return TNMF_OK;
+    if (ctx->ws) {
+        TNMF_HIP_TRY(hipDeviceSynchronize());
+        TNMF_HIP_TRY(hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    if (hipMalloc(&ctx->ws, want) != hipSuccess) {
+        (void)hipGetLastError();
+        return TNMF_E_WORKSPACE;
+    }
+    ctx->ws_bytes = want;
+    return TNMF_OK;
+}
+
+inline char *ws_at(tnmf_hip_ctx *ctx, size_t off) { return static_cast<char *>(ctx->ws) + off; }
+
+bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
+    if (ctx->path == TNMF_PATH_GENERIC) return false;
+    return mfma_supported(g, dtype);
+}
+
+#define ENTER(ctx, geom)                                   \
+    if (!(ctx)) return TNMF_E_NULL;                        \
+    Geo g;                                                 \
+    {                                                      \
+        const int _rc = to_geo((geom), &g);                \
+        if (_rc != TNMF_OK) return _rc;                    \
+    }                                                      \
+    const int dtype = (geom)->dtype;                       \
+    hipStream_t s = static_cast<hipStream_t>(stream);      \
+    TNMF_HIP_TRY(hipSetDevice((ctx)->device));
+
+#define CHECK(rc_expr)                  \
+    do {                                \
+        const int _rc = (rc_expr);      \
+        if (_rc != TNMF_OK) return _rc; \
+    } while (0)
+
+int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
+    if (g.N == 0) return TNMF_OK;
+    if (use_mfma(ctx, g, dtype)) {
+        ctx->last_path = "mfma";
+        return mfma_reconstruct(ctx, g, (const float *)W, (const float *)H, (float *)R, s);
+    }
+    if (ctx->path == TNMF_PATH_MFMA) return TNMF_E_UNSUPPORTED;
+    ctx->last_path = "generic";
+    return generic_reconstruct(ctx, g, dtype, W, H, R, s);
+}
+
+int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *Hio,
+              void *neg, void *pos, bool fused, double reg, hipStream_t s) {
+    if (g.N == 0) return TNMF_OK;
+    if (use_mfma(ctx, g, dtype)) {
+        ctx->last_path = "mfma";
+        return mfma_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio, (float *)neg,
+                           (float *)pos, fused, (float)reg, s);
+    }
+    if (ctx->path == TNMF_PATH_MFMA) return TNMF_E_UNSUPPORTED;
+    ctx->last_path = "generic";
+    return generic_corr_W(ctx, g, dtype, V, R, W, Hio, neg, pos, fused, reg, s);
+}
+
+int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, const void *V, const void *R,
+              const void *H, void *neg, void *pos, hipStream_t s) {
+    double *partials = reinterpret_cast<double *>(ws_at(ctx, sc.part_off));
+    int P;
+    if (g.N == 0) {
+        // empty slice: the sums are zero
+        TNMF_HIP_TRY(hipMemsetAsync(neg, 0, (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype), s));
+        TNMF_HIP_TRY(hipMemsetAsync(pos, 0, (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype), s));
+        return TNMF_OK;
+    }
+    if (use_mfma(ctx, g, dtype)) {
+        ctx->last_path = "mfma";
+        P = mfma_corr_H_chunks(ctx, g);
+        CHECK(mfma_corr_H(ctx, g, (const float *)V, (const float *)R, (const float *)H, partials, P, s));
+    } else {
+        if (ctx->path == TNMF_PATH_MFMA) return TNMF_E_UNSUPPORTED;
+        ctx->last_path = "generic";
+        P = generic_corr_H_chunks(ctx, g);
+        CHECK(generic_corr_H(ctx, g, dtype, V, R, H, partials, P, s));
+    }
+    return finalize_corr_H(g, dtype, partials, P, neg, pos, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tnmf_hip_abi_version(void) { return TNMF_HIP_ABI_VERSION; }
+
+const char *tnmf_hip_strerror(int code) {
+    switch (code) {
+        case TNMF_OK: return "ok";
+        case TNMF_E_NULL: return "tnmf_hip: required pointer is NULL";
+        case TNMF_E_GEOM: return "tnmf_hip: bad geometry";
+        case TNMF_E_DTYPE: return "tnmf_hip: dtype must be 0 (f32) or 1 (f64)";
+        case TNMF_E_WORKSPACE: return "tnmf_hip: scratch allocation failed";
+        case TNMF_E_UNSUPPORTED: return "tnmf_hip: shape not supported by the selected kernel family";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+    return "tnmf_hip: unknown error";
+}
+
+int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out) {
+    if (!out) return TNMF_E_NULL;
+    *out = nullptr;
+    TNMF_HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    TNMF_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    tnmf_hip_ctx *ctx = new (std::nothrow) tnmf_hip_ctx();
+    if (!ctx) return TNMF_E_WORKSPACE;
+    ctx->device = device_id;
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->path = TNMF_PATH_AUTO;
+    ctx->last_path = "none";
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    *out = ctx;
+    return TNMF_OK;
+}
+
+int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx) {
+    if (!ctx) return TNMF_OK;
+    int rc = TNMF_OK;
+    if (ctx->ws) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        const hipError_t e = hipFree(ctx->ws);
+        if (e != hipSuccess) rc = (int)e;
+    }
+    delete ctx;
+    return rc;
+}
+
+int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom) {
+    void *stream = nullptr;
+    ENTER(ctx, geom);
+    (void)s;
+    return ensure_scratch(ctx, plan_scratch(ctx, g, dtype).total);
+}
+
+int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path) {
+    if (!ctx) return TNMF_E_NULL;
+    if (path < TNMF_PATH_AUTO || path > TNMF_PATH_MFMA) return TNMF_E_UNSUPPORTED;
+    ctx->path = path;
+    return TNMF_OK;
+}
+
+const char *tnmf_hip_ctx_last_path(const tnmf_hip_ctx *ctx) { return ctx ? ctx->last_path : "none"; }
+
+int tnmf_hip_reconstruct(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *W, const void *H, void *R,
+                         void *stream) {
+    ENTER(ctx, geom);
+    if (!W || (g.N > 0 && (!H || !R))) return TNMF_E_NULL;
+    return do_reconstruct(ctx, g, dtype, W, H, R, s);
+}
+
+int tnmf_hip_grad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *R_or_null,
+                    const void *W, const void *H, void *neg, void *pos, void *stream) {
+    ENTER(ctx, geom);
+    if (!W || (g.N > 0 && (!V || !neg || !pos))) return TNMF_E_NULL;
+    const void *R = R_or_null;
+    if (!R && g.N > 0) {
+        if (!H) return TNMF_E_NULL;
+        const Scratch sc = plan_scratch(ctx, g, dtype);
+        CHECK(ensure_scratch(ctx, sc.total));
+        void *Rs = ws_at(ctx, sc.r_off);
+        CHECK(do_reconstruct(ctx, g, dtype, W, H, Rs, s));
+        R = Rs;
+    }
+    return do_corr_W(ctx, g, dtype, V, R, W, nullptr, neg, pos, false, 0.0, s);
+}
+
+int tnmf_hip_grad_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *R_or_null,
+                    const void *W, const void *H, void *neg, void *pos, void *stream) {
+    ENTER(ctx, geom);
+    if (!neg || !pos || (g.N > 0 && (!V || !H))) return TNMF_E_NULL;
+    const Scratch sc = plan_scratch(ctx, g, dtype);
+    CHECK(ensure_scratch(ctx, sc.total));
+    const void *R = R_or_null;
+    if (!R && g.N > 0) {
+        if (!W) return TNMF_E_NULL;
+        void *Rs = ws_at(ctx, sc.r_off);
+        CHECK(do_reconstruct(ctx, g, dtype, W, H, Rs, s));
+        R = Rs;
+    }
+    return do_corr_H(ctx, g, dtype, sc, V, R, H, neg, pos, s);
+}
+
+int tnmf_hip_mu_update(tnmf_hip_ctx *ctx, int dtype, void *arr, const void *neg, void *pos, double reg,
+                       size_t n_elems, void *stream) {
+    if (!ctx) return TNMF_E_NULL;
+    if (dtype != 0 && dtype != 1) return TNMF_E_DTYPE;
+    if (n_elems > 0 && (!arr || !neg || !pos)) return TNMF_E_NULL;
+    TNMF_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_mu_update(ctx, dtype, arr, neg, pos, reg, n_elems, static_cast<hipStream_t>(stream));
+}
+
+int tnmf_hip_normalize_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W, void *stream) {
+    ENTER(ctx, geom);
+    if (!W) return TNMF_E_NULL;
+    return launch_apply_normalize_W(g, dtype, W, nullptr, nullptr, 0.0, false, s);
+}
+
+int tnmf_hip_energy(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,
+                    double *out_host, void *stream) {
+    ENTER(ctx, geom);
+    if (!out_host) return TNMF_E_NULL;
+    if (g.N == 0) {
+        *out_host = 0.0;
+        return TNMF_OK;
+    }
+    if (!V || !W || !H) return TNMF_E_NULL;
+    const Scratch sc = plan_scratch(ctx, g, dtype);
+    CHECK(ensure_scratch(ctx, sc.total));
+    void *Rs = ws_at(ctx, sc.r_off);
+    CHECK(do_reconstruct(ctx, g, dtype, W, H, Rs, s));
+    double *red = reinterpret_cast<double *>(ws_at(ctx, sc.red_off));
+    CHECK(launch_half_sqdiff(ctx, dtype, V, Rs, (size_t)g.N * g.C * g.Dy * g.Dx, red, red + kEnergyPartials, s));
+    TNMF_HIP_TRY(hipMemcpyAsync(out_host, red + kEnergyPartials, sizeof(double), hipMemcpyDeviceToHost, s));
+    TNMF_HIP_TRY(hipStreamSynchronize(s));
+    return TNMF_OK;
+}
+
+int tnmf_hip_convolve_multi_1d(tnmf_hip_ctx *ctx, int dtype, int ndim, size_t rows, const int *shape,
+                               const void *in, void *out, void *tmp, const double *kernel0, int len0,
+                               const double *kernel1, int len1, void *stream) {
+    if (!ctx || !shape || !kernel0) return TNMF_E_NULL;
+    if (dtype != 0 && dtype != 1) return TNMF_E_DTYPE;
+    if (ndim != 1 && ndim != 2) return TNMF_E_GEOM;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TNMF_HIP_TRY(hipSetDevice(ctx->device));
+    if (rows == 0) return TNMF_OK;
+    if (!in || !out) return TNMF_E_NULL;
+    if (ndim == 1) return launch_convolve_axis(ctx, dtype, in, out, rows, shape[0], 1, kernel0, len0, s);
+    if (!tmp || !kernel1) return TNMF_E_NULL;
+    // reference order: axis -2 first, then axis -1 (TransformInvariantNMF.py:254; _NumPyBackend.py:60-62)
+    CHECK(launch_convolve_axis(ctx, dtype, in, tmp, rows, shape[0], shape[1], kernel0, len0, s));
+    return launch_convolve_axis(ctx, dtype, tmp, out, rows * (size_t)shape[0], shape[1], 1, kernel1, len1, s);
+}
+
+int tnmf_hip_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, void *H_inout,
+                      void *R_scratch, int r_is_valid, double eps, double sparsity, void *stream) {
+    ENTER(ctx, geom);
+    if (g.N == 0) return TNMF_OK;
+    if (!V || !W || !H_inout) return TNMF_E_NULL;
+    void *Rs = R_scratch;
+    if (!Rs) {
+        if (r_is_valid) return TNMF_E_NULL;
+        const Scratch sc = plan_scratch(ctx, g, dtype);
+        CHECK(ensure_scratch(ctx, sc.total));
+        Rs = ws_at(ctx, sc.r_off);
+    }
+    if (!r_is_valid) CHECK(do_reconstruct(ctx, g, dtype, W, H_inout, Rs, s));
+    double reg = eps;
+    if (sparsity > 0) reg += sparsity;  // TransformInvariantNMF.py:227-230
+    return do_corr_W(ctx, g, dtype, V, Rs, W, H_inout, nullptr, nullptr, true, reg, s);
+}
+
+int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,
+                          void *R_scratch, int r_is_valid, void *negpos, void *stream) {
+    ENTER(ctx, geom);
+    if (!negpos || !W || (g.N > 0 && (!V || !H))) return TNMF_E_NULL;
+    const Scratch sc = plan_scratch(ctx, g, dtype);
+    CHECK(ensure_scratch(ctx, sc.total));
+    if (r_is_valid && !R_scratch) return TNMF_E_NULL;
+    void *Rs = R_scratch ? R_scratch : ws_at(ctx, sc.r_off);
+    if (!r_is_valid) CHECK(do_reconstruct(ctx, g, dtype, W, H, Rs, s));
+    char *np = static_cast<char *>(negpos);
+    const size_t wbytes = (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype);
+    return do_corr_H(ctx, g, dtype, sc, V, Rs, H, np, np + wbytes, s);
+}
+
+int tnmf_hip_apply_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W_inout, void *negpos, double eps,
+                     void *stream) {
+    ENTER(ctx, geom);
+    if (!W_inout || !negpos) return TNMF_E_NULL;
+    char *np = static_cast<char *>(negpos);
+    const size_t wbytes = (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype);
+    return launch_apply_normalize_W(g, dtype, W_inout, np, np + wbytes, eps, true, s);
+}
+
+}  // extern "C"

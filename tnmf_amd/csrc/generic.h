@@ -1,0 +1,27 @@
+// Host-side entry points of generic.hip (see there for the kernels).
+#pragma once
+#include "common.h"
+
+constexpr int kMaxTaps = 127;          // longest 1-D inhibition kernel (2 * range + 1)
+constexpr int kEnergyPartials = 2048;  // per-block partial sums of the energy reduction
+
+int generic_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R,
+                        hipStream_t s);
+// fused == false: writes neg/pos.  fused == true: H = (H * neg) / (pos + reg) in place (neg/pos unused).
+int generic_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W,
+                   void *H_inout, void *neg, void *pos, bool fused, double reg, hipStream_t s);
+// split-K partial sums: doubles, [P][M*C][Ay*Ax][2] in unflipped shift order
+int generic_corr_H_chunks(const tnmf_hip_ctx *ctx, const Geo &g);
+int generic_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *H,
+                   double *partials, int P, hipStream_t s);
+// fixed-order sum of the partials in double; writes neg/pos[M,C,*A] in the reference's (flipped) orientation
+int finalize_corr_H(const Geo &g, int dtype, const double *partials, int P, void *neg, void *pos, hipStream_t s);
+
+int launch_mu_update(const tnmf_hip_ctx *ctx, int dtype, void *arr, const void *neg, void *pos, double reg, size_t n,
+                     hipStream_t s);
+int launch_apply_normalize_W(const Geo &g, int dtype, void *W, const void *neg, void *pos, double eps, bool apply,
+                             hipStream_t s);
+int launch_half_sqdiff(const tnmf_hip_ctx *ctx, int dtype, const void *V, const void *R, size_t n, double *partials,
+                       double *out_dev, hipStream_t s);
+int launch_convolve_axis(const tnmf_hip_ctx *ctx, int dtype, const void *in, void *out, size_t rows, int len,
+                         int inner, const double *kernel_host, int ntaps, hipStream_t s);

@@ -1,0 +1,536 @@
+// generic.hip -- dtype- and shape-generic gfx950 kernels of the shift-invariant MU path (f32 and f64, 1-D and 2-D,
+// any atom/channel/atom-count).  They are the f64 path (the reference's own acceptance tests are float64), the path
+// for shapes the MFMA kernels do not cover, and the in-library cross-check of the MFMA kernels.
+//
+// Index forms (reference: /root/reference/tnmf/backends/NumPy.py):
+//   reconstruct :122-132   R[n,c,y,x] = sum_m sum_{a,b} H[n,m,y+a,x+b] * W[m,c,Ay-1-a,Ax-1-b]
+//   corr_W      :101-119   O[n,m,u,v] = sum_c sum_{a,b} W[m,c,a,b] * X[n,c,u+a-(Ay-1),v+b-(Ax-1)]      X in {V, R}
+//   corr_H      :77-90     G[m,c,a,b] = sum_n sum_{y,x} H[n,m,y+Ay-1-a,x+Ax-1-b] * X[n,c,y,x]          X in {V, R}
+#include "generic.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Tile {
+    int TY, TX;      // output tile (TY * TX == kBlock)
+    int tiles_y, tiles_x;
+};
+
+inline Tile make_tile(int rows, int cols) {
+    Tile t;
+    if (rows == 1) {
+        t.TY = 1;
+        t.TX = kBlock;
+    } else if (cols >= 32 || rows < 16) {
+        t.TY = 8;
+        t.TX = 32;
+    } else {
+        t.TY = 16;
+        t.TX = 16;
+    }
+    t.tiles_y = cdiv(rows, t.TY);
+    t.tiles_x = cdiv(cols, t.TX);
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// reconstruct: one block = one (n, c, output tile); loop over atoms, H tile + halo and flipped W[m,c] in LDS.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reconstruct(Geo g, Tile t, const T *__restrict__ W,
+                                                        const T *__restrict__ H, T *__restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *Hs = reinterpret_cast<T *>(smem_raw);
+    const int SH = t.TY + g.Ay - 1, SW = t.TX + g.Ax - 1;
+    const int nA = g.Ay * g.Ax;
+    T *Ws = Hs + SH * SW;
+
+    unsigned bid = blockIdx.x;
+    const int txi = bid % t.tiles_x;
+    bid /= t.tiles_x;
+    const int tyi = bid % t.tiles_y;
+    bid /= t.tiles_y;
+    const int c = bid % g.C;
+    const int n = bid / g.C;
+
+    const int y0 = tyi * t.TY, x0 = txi * t.TX;
+    const int ty = threadIdx.x / t.TX, tx = threadIdx.x % t.TX;
+
+    T acc = T(0);
+    for (int m = 0; m < g.M; ++m) {
+        const T *h = H + ((size_t)n * g.M + m) * g.Hy * g.Hx;
+        const T *w = W + ((size_t)m * g.C + c) * nA;
+        __syncthreads();
+        for (int i = threadIdx.x; i < SH * SW; i += kBlock) {
+            const int r = i / SW, q = i - r * SW;
+            const int hy = y0 + r, hx = x0 + q;
+            Hs[i] = (hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hx + hx] : T(0);
+        }
+        for (int i = threadIdx.x; i < nA; i += kBlock) Ws[i] = w[nA - 1 - i];  // flipped atom
+        __syncthreads();
+        for (int a = 0; a < g.Ay; ++a) {
+            const T *hr = Hs + (ty + a) * SW + tx;
+            const T *wr = Ws + a * g.Ax;
+            for (int b = 0; b < g.Ax; ++b) acc += hr[b] * wr[b];
+        }
+    }
+    const int y = y0 + ty, x = x0 + tx;
+    if (y < g.Dy && x < g.Dx) R[(((size_t)n * g.C + c) * g.Dy + y) * g.Dx + x] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// corr_W (H gradient): one block = one (n, m, tile of the shift plane); loop over channels, zero-padded V and R
+// tiles in LDS.  FUSED: H = (H * neg) / (pos + reg) in place instead of writing neg/pos.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_corr_W(Geo g, Tile t, const T *__restrict__ V, const T *__restrict__ Rr,
+                                                   const T *__restrict__ W, T *__restrict__ Hio,
+                                                   T *__restrict__ neg, T *__restrict__ pos, T reg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int SH = t.TY + g.Ay - 1, SW = t.TX + g.Ax - 1;
+    const int nA = g.Ay * g.Ax;
+    T *Vs = reinterpret_cast<T *>(smem_raw);
+    T *Rs = Vs + SH * SW;
+    T *Ws = Rs + SH * SW;
+
+    unsigned bid = blockIdx.x;
+    const int txi = bid % t.tiles_x;
+    bid /= t.tiles_x;
+    const int tyi = bid % t.tiles_y;
+    bid /= t.tiles_y;
+    const int m = bid % g.M;
+    const int n = bid / g.M;
+
+    const int u0 = tyi * t.TY, v0 = txi * t.TX;
+    const int ty = threadIdx.x / t.TX, tx = threadIdx.x % t.TX;
+
+    T an = T(0), ap = T(0);
+    for (int c = 0; c < g.C; ++c) {
+        const T *v = V + ((size_t)n * g.C + c) * g.Dy * g.Dx;
+        const T *r = Rr + ((size_t)n * g.C + c) * g.Dy * g.Dx;
+        const T *w = W + ((size_t)m * g.C + c) * nA;
+        __syncthreads();
+        for (int i = threadIdx.x; i < SH * SW; i += kBlock) {
+            const int rr = i / SW, q = i - rr * SW;
+            const int y = u0 + rr - (g.Ay - 1), x = v0 + q - (g.Ax - 1);
+            const bool in = (y >= 0 && y < g.Dy && x >= 0 && x < g.Dx);
+            const size_t o = (size_t)y * g.Dx + x;
+            Vs[i] = in ? v[o] : T(0);
+            Rs[i] = in ? r[o] : T(0);
+        }
+        for (int i = threadIdx.x; i < nA; i += kBlock) Ws[i] = w[i];
+        __syncthreads();
+        for (int a = 0; a < g.Ay; ++a) {
+            const T *vr = Vs + (ty + a) * SW + tx;
+            const T *rr = Rs + (ty + a) * SW + tx;
+            const T *wr = Ws + a * g.Ax;
+            for (int b = 0; b < g.Ax; ++b) {
+                an += wr[b] * vr[b];
+                ap += wr[b] * rr[b];
+            }
+        }
+    }
+    const int u = u0 + ty, vv = v0 + tx;
+    if (u < g.Hy && vv < g.Hx) {
+        const size_t o = (((size_t)n * g.M + m) * g.Hy + u) * g.Hx + vv;
+        if (FUSED) {
+            const T h = Hio[o];
+            Hio[o] = (h * an) / (ap + reg);
+        } else {
+            neg[o] = an;
+            pos[o] = ap;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// corr_H (W gradient), stage 1: grid (P, M*C).  Block p walks work items (n, tile) = p, p+P, ...; per item the H
+// tile (+halo) of atom m and the V, R tiles of channel c sit in LDS; thread (group, shift) sums its shift over the
+// group's pixels in T, then folds the item's partial into a double.  Output: partials[p][mc][shift][2] (double).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kMaxShiftsPerThread = 4;  // atoms up to 4 * 256 = 1024 shifts (e.g. 32 x 32)
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_corr_H(Geo g, Tile t, int P, const T *__restrict__ V,
+                                                   const T *__restrict__ Rr, const T *__restrict__ H,
+                                                   double *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int SH = t.TY + g.Ay - 1, SW = t.TX + g.Ax - 1;
+    const int nA = g.Ay * g.Ax;
+    const int npix = t.TY * t.TX;
+    T *Hs = reinterpret_cast<T *>(smem_raw);
+    T *Vs = Hs + SH * SW;
+    T *Rs = Vs + npix;
+
+    const int p = blockIdx.x;
+    const int mc = blockIdx.y;
+    const int m = mc / g.C, c = mc % g.C;
+
+    const int gs = nA < kBlock ? nA : kBlock;  // threads per group = shifts handled side by side
+    const int G = kBlock / gs;                 // pixel groups
+    const int grp = threadIdx.x / gs, sl = threadIdx.x - grp * gs;
+    const bool active = grp < G;
+
+    double accn[kMaxShiftsPerThread], accp[kMaxShiftsPerThread];
+#pragma unroll
+    for (int k = 0; k < kMaxShiftsPerThread; ++k) accn[k] = accp[k] = 0.0;
+
+    const int items = g.N * t.tiles_y * t.tiles_x;
+    for (int it = p; it < items; it += P) {
+        int r = it;
+        const int txi = r % t.tiles_x;
+        r /= t.tiles_x;
+        const int tyi = r % t.tiles_y;
+        const int n = r / t.tiles_y;
+        const int y0 = tyi * t.TY, x0 = txi * t.TX;
+        const T *h = H + ((size_t)n * g.M + m) * g.Hy * g.Hx;
+        const T *v = V + ((size_t)n * g.C + c) * g.Dy * g.Dx;
+        const T *rr = Rr + ((size_t)n * g.C + c) * g.Dy * g.Dx;
+        __syncthreads();
+        for (int i = threadIdx.x; i < SH * SW; i += kBlock) {
+            const int a = i / SW, q = i - a * SW;
+            const int hy = y0 + a, hx = x0 + q;
+            Hs[i] = (hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hx + hx] : T(0);
+        }
+        for (int i = threadIdx.x; i < npix; i += kBlock) {
+            const int a = i / t.TX, q = i - a * t.TX;
+            const int y = y0 + a, x = x0 + q;
+            const bool in = (y < g.Dy && x < g.Dx);
+            const size_t o = (size_t)y * g.Dx + x;
+            Vs[i] = in ? v[o] : T(0);
+            Rs[i] = in ? rr[o] : T(0);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < kMaxShiftsPerThread; ++k) {
+                const int s = sl + k * gs;
+                if (s < nA) {
+                    const int a = s / g.Ax, b = s - a * g.Ax;
+                    T pn = T(0), pp = T(0);
+                    for (int pix = grp; pix < npix; pix += G) {
+                        const int y = pix / t.TX, x = pix - y * t.TX;
+                        const T hv = Hs[(y + a) * SW + x + b];
+                        pn += hv * Vs[pix];
+                        pp += hv * Rs[pix];
+                    }
+                    accn[k] += (double)pn;
+                    accp[k] += (double)pp;
+                }
+            }
+        }
+    }
+    // fold the pixel groups (fixed order) and write this block's partial
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(smem_raw);  // [G][nA][2], reuses the tiles
+#pragma unroll
+    for (int k = 0; k < kMaxShiftsPerThread; ++k) {
+        const int s = sl + k * gs;
+        if (active && s < nA) {
+            red[((size_t)grp * nA + s) * 2 + 0] = accn[k];
+            red[((size_t)grp * nA + s) * 2 + 1] = accp[k];
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nA; s += kBlock) {
+        double sn = 0.0, sp = 0.0;
+        for (int q = 0; q < G; ++q) {
+            sn += red[((size_t)q * nA + s) * 2 + 0];
+            sp += red[((size_t)q * nA + s) * 2 + 1];
+        }
+        double *out = partials + (((size_t)p * (g.M * g.C) + mc) * nA + s) * 2;
+        out[0] = sn;
+        out[1] = sp;
+    }
+}
+
+}  // namespace
+
+// stage 2 of every W gradient (generic and MFMA): sum the P partials in fixed order, in double; shift s of the
+// partial layout is the *unflipped* offset (a', b') = (Ay-1-a, Ax-1-b), so the flip is a reversed linear index.
+template <typename T>
+__global__ void k_corr_H_finalize(int MC, int nA, int P, const double *__restrict__ partials, T *__restrict__ neg,
+                                  T *__restrict__ pos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MC * nA) return;
+    const int mc = i / nA, s = i - mc * nA;
+    double sn = 0.0, sp = 0.0;
+    for (int p = 0; p < P; ++p) {
+        const double *in = partials + (((size_t)p * MC + mc) * nA + s) * 2;
+        sn += in[0];
+        sp += in[1];
+    }
+    const size_t o = (size_t)mc * nA + (nA - 1 - s);
+    neg[o] = (T)sn;
+    pos[o] = (T)sp;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// elementwise / small kernels
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ void k_mu_update(T *__restrict__ arr, const T *__restrict__ neg, T *__restrict__ pos, T reg, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T p = pos[i] + reg;
+        pos[i] = p;
+        arr[i] = (arr[i] * neg[i]) / p;
+    }
+}
+
+template <typename T>
+__device__ double block_sum(double v, double *sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double tot = 0.0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) tot += sh[w];  // every thread, same order
+    return tot;
+}
+
+// W[mc, :] = (W * neg) / (pos + eps) if APPLY, then W[mc, :] /= sum.  One block per (m, c) row.
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(kBlock) void k_apply_normalize_W(int nA, T *__restrict__ W, const T *__restrict__ neg,
+                                                              T *__restrict__ pos, T eps) {
+    __shared__ double sh[kBlock / 64];
+    const size_t base = (size_t)blockIdx.x * nA;
+    double part = 0.0;
+    for (int i = threadIdx.x; i < nA; i += kBlock) {
+        T w = W[base + i];
+        if (APPLY) {
+            const T p = pos[base + i] + eps;
+            pos[base + i] = p;
+            w = (w * neg[base + i]) / p;
+            W[base + i] = w;
+        }
+        part += (double)w;
+    }
+    const T tot = (T)block_sum<T>(part, sh);
+    for (int i = threadIdx.x; i < nA; i += kBlock) W[base + i] = W[base + i] / tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sqdiff_partial(const T *__restrict__ V, const T *__restrict__ R, size_t n,
+                                                           double *__restrict__ partial) {
+    __shared__ double sh[kBlock / 64];
+    double acc = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T d = V[i] - R[i];
+        acc += (double)d * (double)d;
+    }
+    const double tot = block_sum<T>(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_partials(const double *__restrict__ partial, int n, double scale,
+                                                         double *__restrict__ out) {
+    __shared__ double sh[kBlock / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) acc += partial[i];
+    const double tot = block_sum<double>(acc, sh);
+    if (threadIdx.x == 0) *out = scale * tot;
+}
+
+// zero-padded 'same' 1-D convolution along one axis of arr[rows, len, inner] (scipy.ndimage.convolve1d, mode='constant'):
+//   out[r, i, j] = sum_t k[t] * in[r, i + rad - t, j]
+struct Taps {
+    double k[kMaxTaps];
+};
+
+template <typename T>
+__global__ void k_convolve_axis(const T *__restrict__ in, T *__restrict__ out, size_t rows, int len, int inner,
+                                Taps taps, int ntaps) {
+    const size_t total = rows * (size_t)len * inner;
+    const int rad = (ntaps - 1) / 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int j = (int)(e % inner);
+        const size_t rest = e / inner;
+        const int i = (int)(rest % len);
+        const size_t r = rest / len;
+        const T *line = in + r * (size_t)len * inner + j;
+        T acc = T(0);
+        for (int t = 0; t < ntaps; ++t) {
+            const int src = i + rad - t;
+            if (src >= 0 && src < len) acc += (T)taps.k[t] * line[(size_t)src * inner];
+        }
+        out[e] = acc;
+    }
+}
+
+inline int grid_for(size_t n, const tnmf_hip_ctx *ctx) {
+    const size_t want = (n + kBlock - 1) / kBlock;
+    const size_t cap = (size_t)ctx->num_cu * 8;
+    return (int)(want < cap ? (want ? want : 1) : cap);
+}
+
+template <typename T>
+int launch_reconstruct(const Geo &g, const void *W, const void *H, void *R, hipStream_t s) {
+    const Tile t = make_tile(g.Dy, g.Dx);
+    const size_t lds = ((size_t)(t.TY + g.Ay - 1) * (t.TX + g.Ax - 1) + (size_t)g.Ay * g.Ax) * sizeof(T);
+    if (lds > 64 * 1024) return TNMF_E_UNSUPPORTED;
+    const size_t blocks = (size_t)g.N * g.C * t.tiles_y * t.tiles_x;
+    if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
+    hipLaunchKernelGGL(k_reconstruct<T>, dim3((unsigned)blocks), dim3(kBlock), lds, s, g, t, (const T *)W,
+                       (const T *)H, (T *)R);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+template <typename T>
+int launch_corr_W(const Geo &g, const void *V, const void *R, const void *W, void *Hio, void *neg, void *pos,
+                  bool fused, double reg, hipStream_t s) {
+    const Tile t = make_tile(g.Hy, g.Hx);
+    const size_t lds = (2 * (size_t)(t.TY + g.Ay - 1) * (t.TX + g.Ax - 1) + (size_t)g.Ay * g.Ax) * sizeof(T);
+    if (lds > 64 * 1024) return TNMF_E_UNSUPPORTED;
+    const size_t blocks = (size_t)g.N * g.M * t.tiles_y * t.tiles_x;
+    if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
+    if (fused)
+        hipLaunchKernelGGL((k_corr_W<T, true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, g, t, (const T *)V,
+                           (const T *)R, (const T *)W, (T *)Hio, (T *)nullptr, (T *)nullptr, (T)reg);
+    else
+        hipLaunchKernelGGL((k_corr_W<T, false>), dim3((unsigned)blocks), dim3(kBlock), lds, s, g, t, (const T *)V,
+                           (const T *)R, (const T *)W, (T *)nullptr, (T *)neg, (T *)pos, (T)0);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+template <typename T>
+int launch_corr_H(const Geo &g, const void *V, const void *R, const void *H, double *partials, int P,
+                  hipStream_t s) {
+    const Tile t = make_tile(g.Dy, g.Dx);
+    const int nA = g.Ay * g.Ax;
+    if (nA > kBlock * kMaxShiftsPerThread) return TNMF_E_UNSUPPORTED;
+    const int gs = nA < kBlock ? nA : kBlock;
+    const int G = kBlock / gs;
+    size_t lds = ((size_t)(t.TY + g.Ay - 1) * (t.TX + g.Ax - 1) + 2 * (size_t)t.TY * t.TX) * sizeof(T);
+    const size_t red = (size_t)G * nA * 2 * sizeof(double);
+    if (red > lds) lds = red;
+    if (lds > 64 * 1024) return TNMF_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_corr_H<T>, dim3(P, g.M * g.C), dim3(kBlock), lds, s, g, t, P, (const T *)V, (const T *)R,
+                       (const T *)H, partials);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// host entry points used by api.hip
+// ------------------------------------------------------------------------------------------------------------
+int generic_reconstruct(tnmf_hip_ctx *, const Geo &g, int dtype, const void *W, const void *H, void *R,
+                        hipStream_t s) {
+    return dtype == 0 ? launch_reconstruct<float>(g, W, H, R, s) : launch_reconstruct<double>(g, W, H, R, s);
+}
+
+int generic_corr_W(tnmf_hip_ctx *, const Geo &g, int dtype, const void *V, const void *R, const void *W,
+                   void *H_inout, void *neg, void *pos, bool fused, double reg, hipStream_t s) {
+    return dtype == 0 ? launch_corr_W<float>(g, V, R, W, H_inout, neg, pos, fused, reg, s)
+                      : launch_corr_W<double>(g, V, R, W, H_inout, neg, pos, fused, reg, s);
+}
+
+int generic_corr_H_chunks(const tnmf_hip_ctx *ctx, const Geo &g) {
+    const Tile t = make_tile(g.Dy, g.Dx);
+    const long items = (long)g.N * t.tiles_y * t.tiles_x;
+    long P = ((long)ctx->num_cu * 8 + (long)g.M * g.C - 1) / ((long)g.M * g.C);  // ~8 blocks per CU in total
+    if (P < 1) P = 1;
+    if (P > items) P = items;
+    if (P > 4096) P = 4096;
+    return (int)P;
+}
+
+int generic_corr_H(tnmf_hip_ctx *, const Geo &g, int dtype, const void *V, const void *R, const void *H,
+                   double *partials, int P, hipStream_t s) {
+    return dtype == 0 ? launch_corr_H<float>(g, V, R, H, partials, P, s)
+                      : launch_corr_H<double>(g, V, R, H, partials, P, s);
+}
+
+int finalize_corr_H(const Geo &g, int dtype, const double *partials, int P, void *neg, void *pos, hipStream_t s) {
+    const int MC = g.M * g.C, nA = g.Ay * g.Ax;
+    const int blocks = cdiv(MC * nA, kBlock);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_corr_H_finalize<float>, dim3(blocks), dim3(kBlock), 0, s, MC, nA, P, partials,
+                           (float *)neg, (float *)pos);
+    else
+        hipLaunchKernelGGL(k_corr_H_finalize<double>, dim3(blocks), dim3(kBlock), 0, s, MC, nA, P, partials,
+                           (double *)neg, (double *)pos);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int launch_mu_update(const tnmf_hip_ctx *ctx, int dtype, void *arr, const void *neg, void *pos, double reg, size_t n,
+                     hipStream_t s) {
+    if (n == 0) return TNMF_OK;
+    const int grid = grid_for(n, ctx);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_mu_update<float>, dim3(grid), dim3(kBlock), 0, s, (float *)arr, (const float *)neg,
+                           (float *)pos, (float)reg, n);
+    else
+        hipLaunchKernelGGL(k_mu_update<double>, dim3(grid), dim3(kBlock), 0, s, (double *)arr, (const double *)neg,
+                           (double *)pos, reg, n);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int launch_apply_normalize_W(const Geo &g, int dtype, void *W, const void *neg, void *pos, double eps, bool apply,
+                             hipStream_t s) {
+    const int nA = g.Ay * g.Ax, rows = g.M * g.C;
+    if (dtype == 0) {
+        if (apply)
+            hipLaunchKernelGGL((k_apply_normalize_W<float, true>), dim3(rows), dim3(kBlock), 0, s, nA, (float *)W,
+                               (const float *)neg, (float *)pos, (float)eps);
+        else
+            hipLaunchKernelGGL((k_apply_normalize_W<float, false>), dim3(rows), dim3(kBlock), 0, s, nA, (float *)W,
+                               (const float *)nullptr, (float *)nullptr, 0.f);
+    } else {
+        if (apply)
+            hipLaunchKernelGGL((k_apply_normalize_W<double, true>), dim3(rows), dim3(kBlock), 0, s, nA, (double *)W,
+                               (const double *)neg, (double *)pos, eps);
+        else
+            hipLaunchKernelGGL((k_apply_normalize_W<double, false>), dim3(rows), dim3(kBlock), 0, s, nA, (double *)W,
+                               (const double *)nullptr, (double *)nullptr, 0.0);
+    }
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int launch_half_sqdiff(const tnmf_hip_ctx *ctx, int dtype, const void *V, const void *R, size_t n, double *partials,
+                       double *out_dev, hipStream_t s) {
+    int grid = grid_for(n, ctx);
+    if (grid > kEnergyPartials) grid = kEnergyPartials;
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_sqdiff_partial<float>, dim3(grid), dim3(kBlock), 0, s, (const float *)V,
+                           (const float *)R, n, partials);
+    else
+        hipLaunchKernelGGL(k_sqdiff_partial<double>, dim3(grid), dim3(kBlock), 0, s, (const double *)V,
+                           (const double *)R, n, partials);
+    TNMF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(kBlock), 0, s, partials, grid, 0.5, out_dev);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int launch_convolve_axis(const tnmf_hip_ctx *ctx, int dtype, const void *in, void *out, size_t rows, int len,
+                         int inner, const double *kernel_host, int ntaps, hipStream_t s) {
+    if (ntaps < 1 || ntaps > kMaxTaps || (ntaps & 1) == 0) return TNMF_E_UNSUPPORTED;
+    Taps taps;
+    for (int i = 0; i < kMaxTaps; ++i) taps.k[i] = i < ntaps ? kernel_host[i] : 0.0;
+    const size_t total = rows * (size_t)len * inner;
+    if (total == 0) return TNMF_OK;
+    const int grid = grid_for(total, ctx);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_convolve_axis<float>, dim3(grid), dim3(kBlock), 0, s, (const float *)in, (float *)out,
+                           rows, len, inner, taps, ntaps);
+    else
+        hipLaunchKernelGGL(k_convolve_axis<double>, dim3(grid), dim3(kBlock), 0, s, (const double *)in,
+                           (double *)out, rows, len, inner, taps, ntaps);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
