@@ -79,9 +79,15 @@ int ensure_scratch(tnmf_hip_ctx *ctx, size_t bytes) {
 
 inline char *ws_at(tnmf_hip_ctx *ctx, size_t off) { return static_cast<char *>(ctx->ws) + off; }
 
-bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
+enum Prim { kReconstruct, kCorrW, kCorrH };
+
+bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
     if (ctx->path == TNMF_PATH_GENERIC) return false;
-    return mfma_supported(g, dtype);
+    switch (prim) {
+        case kReconstruct: return mfma_has_reconstruct(g, dtype);
+        case kCorrW: return mfma_has_corr_W(g, dtype);
+        default: return mfma_has_corr_H(g, dtype);
+    }
 }
 
 #define ENTER(ctx, geom)                                   \
@@ -103,7 +109,7 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
 
 int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
-    if (use_mfma(ctx, g, dtype)) {
+    if (use_mfma(ctx, g, dtype, kReconstruct)) {
         ctx->last_path = "mfma";
         return mfma_reconstruct(ctx, g, (const float *)W, (const float *)H, (float *)R, s);
     }
@@ -115,7 +121,7 @@ int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, co
 int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *Hio,
               void *neg, void *pos, bool fused, double reg, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
-    if (use_mfma(ctx, g, dtype)) {
+    if (use_mfma(ctx, g, dtype, kCorrW)) {
         ctx->last_path = "mfma";
         return mfma_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio, (float *)neg,
                            (float *)pos, fused, (float)reg, s);
@@ -135,7 +141,7 @@ int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, con
         TNMF_HIP_TRY(hipMemsetAsync(pos, 0, (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype), s));
         return TNMF_OK;
     }
-    if (use_mfma(ctx, g, dtype)) {
+    if (use_mfma(ctx, g, dtype, kCorrH)) {
         ctx->last_path = "mfma";
         P = mfma_corr_H_chunks(ctx, g);
         CHECK(mfma_corr_H(ctx, g, (const float *)V, (const float *)R, (const float *)H, partials, P, s));

@@ -2,7 +2,10 @@
 #pragma once
 #include "common.h"
 
-bool mfma_supported(const Geo &g, int dtype);
+// per-primitive shape support of the MFMA family (float32 only)
+bool mfma_has_reconstruct(const Geo &g, int dtype);
+bool mfma_has_corr_W(const Geo &g, int dtype);
+bool mfma_has_corr_H(const Geo &g, int dtype);
 int mfma_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, const float *W, const float *H, float *R, hipStream_t s);
 int mfma_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *W, float *H_inout,
                 float *neg, float *pos, bool fused, float reg, hipStream_t s);

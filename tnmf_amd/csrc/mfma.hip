@@ -1,16 +1,547 @@
-// mfma.hip -- f32 MFMA kernels (placeholder until the first generic path is parity-green on the GPU).
+// mfma.hip -- float32 kernels of the shift-invariant MU path on the gfx950 matrix cores.
+//
+// All three primitives are written as implicit GEMMs on v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (exact f32:
+// a k-ordered fmaf chain, cdna_hip_programming.md section 3), operands staged through LDS, no im2col in memory.
+//
+//   corr_W  (H gradient, NumPy.py:101-119)   D[atom m][pixel v]        K = (c, a, b)      A = W          B = X window
+//   corr_H  (W gradient, NumPy.py:77-90)     D[atom m][shift (c,a',b')] K = H pixel (r,t)  A = H          B = shifted X
+//   reconstruct (NumPy.py:122-132)           D[(c, a)][pixel t]        K = (m, b)         A = flipped W  B = H window
+//                                            followed by an in-register/LDS "col2im" along the row axis.
+//
+// Operand maps used (lane l of the wave64):
+//   32x32x2 : A[i = l&31][k = l>>5]   B[k = l>>5][j = l&31]   D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31], r = 0..15
+//   16x16x4 : A[i = l&15][k = l>>4]   B[k = l>>4][j = l&15]   D[row = 4*(l>>4) + r][col = l&15],           r = 0..3
 #include "mfma.h"
 
-bool mfma_supported(const Geo &, int) { return false; }
-int mfma_reconstruct(tnmf_hip_ctx *, const Geo &, const float *, const float *, float *, hipStream_t) {
-    return TNMF_E_UNSUPPORTED;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kBlock = 256;   // 4 waves
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
 }
-int mfma_corr_W(tnmf_hip_ctx *, const Geo &, const float *, const float *, const float *, float *, float *, float *,
-                bool, float, hipStream_t) {
-    return TNMF_E_UNSUPPORTED;
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
-int mfma_corr_H_chunks(const tnmf_hip_ctx *, const Geo &) { return 0; }
-int mfma_corr_H(tnmf_hip_ctx *, const Geo &, const float *, const float *, const float *, double *, int,
-                hipStream_t) {
-    return TNMF_E_UNSUPPORTED;
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ================================================================================================================
+// corr_W: one workgroup = 32 atoms x (CW_TY rows x 32 cols) of the shift plane of one sample.
+//   wave w owns rows w*CW_RB .. w*CW_RB+CW_RB-1 of the tile, for V and for R: 2*CW_RB accumulators of 32x32.
+//   per channel: zero-padded V and R windows (row stride CW_XSTR) and W[32 atoms][Ay][Axp] (Ax padded to even with
+//   zero taps, so that the two k of one MFMA sit in the same atom row) are staged in LDS.
+// ================================================================================================================
+constexpr int CW_TY = 16, CW_TX = 32, CW_RB = 4, CW_XSTR = 64;
+
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_mfma_corr_W(Geo g, int tiles_y, int tiles_x, int MT,
+                                                        const float *__restrict__ V, const float *__restrict__ Rr,
+                                                        const float *__restrict__ W, float *__restrict__ Hio,
+                                                        float *__restrict__ neg, float *__restrict__ pos, float reg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Axp = (g.Ax + 1) & ~1;
+    const int SH = CW_TY + g.Ay - 1;
+    const int KC = g.Ay * Axp;
+    float *Vs = smem;
+    float *Rs = Vs + SH * CW_XSTR;
+    float *Ws = Rs + SH * CW_XSTR;   // [KC][32]
+
+    unsigned bid = blockIdx.x;
+    const int txi = bid % tiles_x;
+    bid /= tiles_x;
+    const int tyi = bid % tiles_y;
+    bid /= tiles_y;
+    const int mt = bid % MT;
+    const int n = bid / MT;
+    const int u0 = tyi * CW_TY, v0 = txi * CW_TX;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int nA = g.Ay * g.Ax;
+    const int need_w = CW_TX + Axp - 1;
+
+    f32x16 an[CW_RB], ap[CW_RB];
+#pragma unroll
+    for (int rb = 0; rb < CW_RB; ++rb) {
+        an[rb] = zero16();
+        ap[rb] = zero16();
+    }
+
+    for (int c = 0; c < g.C; ++c) {
+        const float *v = V + ((size_t)n * g.C + c) * g.Dy * g.Dx;
+        const float *r = Rr + ((size_t)n * g.C + c) * g.Dy * g.Dx;
+        __syncthreads();
+        for (int i = threadIdx.x; i < SH * CW_XSTR; i += kBlock) {
+            const int rr = i / CW_XSTR, q = i - rr * CW_XSTR;
+            const int y = u0 + rr - (g.Ay - 1), x = v0 + q - (g.Ax - 1);
+            const bool in = (q < need_w) && y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
+            const size_t o = (size_t)y * g.Dx + x;
+            Vs[i] = in ? v[o] : 0.f;
+            Rs[i] = in ? r[o] : 0.f;
+        }
+        for (int i = threadIdx.x; i < KC * 32; i += kBlock) {
+            const int kk = i >> 5, mi = i & 31;
+            const int a = kk / Axp, b = kk - a * Axp;
+            const int m = mt * 32 + mi;
+            Ws[i] = (b < g.Ax && m < g.M) ? W[((size_t)m * g.C + c) * nA + a * g.Ax + b] : 0.f;
+        }
+        __syncthreads();
+
+        const float *vb = Vs + (wave * CW_RB) * CW_XSTR + j + h;
+        const float *rb_ = Rs + (wave * CW_RB) * CW_XSTR + j + h;
+        const float *wb = Ws + h * 32 + j;
+        for (int a = 0; a < g.Ay; ++a) {
+            const float *va = vb + a * CW_XSTR;
+            const float *ra = rb_ + a * CW_XSTR;
+            const float *wa = wb + a * Axp * 32;
+            for (int b2 = 0; b2 < Axp; b2 += 2) {
+                const float wv = wa[b2 * 32];
+#pragma unroll
+                for (int rb = 0; rb < CW_RB; ++rb) {
+                    an[rb] = mfma32(wv, va[rb * CW_XSTR + b2], an[rb]);
+                    ap[rb] = mfma32(wv, ra[rb * CW_XSTR + b2], ap[rb]);
+                }
+            }
+        }
+    }
+
+    const int vv = v0 + j;
+    if (vv < g.Hx) {
+#pragma unroll
+        for (int rb = 0; rb < CW_RB; ++rb) {
+            const int u = u0 + wave * CW_RB + rb;
+            if (u < g.Hy) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < g.M) {
+                        const size_t o = (((size_t)n * g.M + m) * g.Hy + u) * g.Hx + vv;
+                        if (FUSED) {
+                            const float hv = Hio[o];
+                            Hio[o] = (hv * an[rb][r]) / (ap[rb][r] + reg);
+                        } else {
+                            neg[o] = an[rb][r];
+                            pos[o] = ap[rb][r];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================================
+// corr_H: grid (P, MT, JG).  Work item = (sample n, CH_RH rows x CH_TW cols of the shift plane).  A = the H tile of
+//   32 atoms; B[k = pixel (r,t)][j = column J] = X[c][r - a'][t - b'] with J = c*nA + a'*Ax + b' (zero outside the
+//   sample).  Wave w takes row w of the tile (the waves split K), every wave owns all NT column tiles of its column
+//   group jg for both V and R: 2*NT accumulators of 32x32.  X row stride = CH_TW + Ax, i.e. == Ax (mod 32), so that the
+//   32 columns of one MFMA (consecutive J) read 32 consecutive LDS words.
+//   Output: partials[p][m*C + c][s = a'*Ax + b'][{V, R}] in double (summed in fixed order by k_corr_H_finalize).
+// ================================================================================================================
+constexpr int CH_RH = 4, CH_TW = 64, CH_AST = CH_RH * CH_TW + 1;
+
+template <int NT>
+__global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, int P, int rblocks, int cblocks,
+                                                        const float *__restrict__ V, const float *__restrict__ Rr,
+                                                        const float *__restrict__ H, double *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int XST = CH_TW + g.Ax;
+    const int XR = CH_RH + g.Ay - 1;
+    const int plane = XR * XST;          // one channel of one of V / R
+    float *Hs = smem;                    // [32][CH_AST]
+    float *Xv = Hs + 32 * CH_AST;        // [C][XR][XST]
+    float *Xr = Xv + g.C * plane;        // [C][XR][XST]
+    float *zero = Xr + g.C * plane;      // one zero word (+pad): target of out-of-range columns
+
+    const int p = blockIdx.x, mt = blockIdx.y, jg = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int nA = g.Ay * g.Ax;
+    const int J = g.C * nA;
+
+    // per-lane B-operand base (in floats, relative to Xv / Xr) for each of the NT column tiles; -1 => zero word
+    int boff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = (jg * NT + t) * 32 + j;
+        if (col < J) {
+            const int c = col / nA, s = col - c * nA;
+            const int a = s / g.Ax, b = s - a * g.Ax;
+            boff[t] = c * plane + (wave + (g.Ay - 1) - a) * XST + (g.Ax - 1) - b + h;
+        } else {
+            boff[t] = -1;
+        }
+    }
+
+    f32x16 accv[NT], accr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        accv[t] = zero16();
+        accr[t] = zero16();
+    }
+    if (threadIdx.x < 8) zero[threadIdx.x] = 0.f;
+
+    const int items = g.N * rblocks * cblocks;
+    for (int it = p; it < items; it += P) {
+        int q = it;
+        const int cbi = q % cblocks;
+        q /= cblocks;
+        const int rbi = q % rblocks;
+        const int n = q / rblocks;
+        const int r0 = rbi * CH_RH, t0 = cbi * CH_TW;
+
+        __syncthreads();
+        // H tile: 32 atoms x CH_RH rows x CH_TW cols
+        for (int i = threadIdx.x; i < 32 * CH_RH * CH_TW; i += kBlock) {
+            const int col = i % CH_TW;
+            const int row = (i / CH_TW) % CH_RH;
+            const int mi = i / (CH_TW * CH_RH);
+            const int m = mt * 32 + mi, r = r0 + row, t = t0 + col;
+            const bool in = m < g.M && r < g.Hy && t < g.Hx;
+            Hs[mi * CH_AST + row * CH_TW + col] = in ? H[(((size_t)n * g.M + m) * g.Hy + r) * g.Hx + t] : 0.f;
+        }
+        // zero-padded V and R windows: rows r0-(Ay-1) .. r0+RH-1, cols t0-(Ax-1) .. t0+TW-1 (+1 pad column)
+        for (int i = threadIdx.x; i < g.C * plane; i += kBlock) {
+            const int c = i / plane;
+            const int rem = i - c * plane;
+            const int row = rem / XST, col = rem - row * XST;
+            const int y = r0 - (g.Ay - 1) + row, x = t0 - (g.Ax - 1) + col;
+            const bool in = y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
+            const size_t o = (((size_t)n * g.C + c) * g.Dy + y) * g.Dx + x;
+            Xv[i] = in ? V[o] : 0.f;
+            Xr[i] = in ? Rr[o] : 0.f;
+        }
+        __syncthreads();
+
+        const float *ha = Hs + j * CH_AST + wave * CH_TW + h;
+        for (int k2 = 0; k2 < CH_TW; k2 += 2) {
+            const float hv = ha[k2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float *bv = boff[t] >= 0 ? Xv + boff[t] + k2 : zero;
+                const float *br = boff[t] >= 0 ? Xr + boff[t] + k2 : zero;
+                accv[t] = mfma32(hv, *bv, accv[t]);
+                accr[t] = mfma32(hv, *br, accr[t]);
+            }
+        }
+    }
+
+    // fold the 4 waves (they split K) through LDS in fixed order, then write this block's partial in double
+    __syncthreads();
+    float *red = smem;   // [4 waves][32 rows? no: per wave NT*2*16 regs x 64 lanes] -> reduce tile by tile
+    const int MC = g.M * g.C;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        // stage: red[wave][which][r][lane]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            red[((wave * 2 + 0) * 16 + r) * 64 + lane] = accv[t][r];
+            red[((wave * 2 + 1) * 16 + r) * 64 + lane] = accr[t][r];
+        }
+        __syncthreads();
+        // thread -> (which, r, lane'): 2*16*64 = 2048 values, 8 per thread
+        for (int e = threadIdx.x; e < 2 * 16 * 64; e += kBlock) {
+            const int ln = e & 63, r = (e >> 6) & 15, which = e >> 10;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += (double)red[((w * 2 + which) * 16 + r) * 64 + ln];
+            const int col = (jg * NT + t) * 32 + (ln & 31);
+            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+            if (col < J && m < g.M) {
+                const int c = col / nA, sft = col - c * nA;
+                partials[(((size_t)p * MC + (size_t)m * g.C + c) * nA + sft) * 2 + which] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================================================================
+// reconstruct: R[c][y][x] = sum_{m,a,b} H[m][y+a][x+b] * Wf[m][c][a][b]  (Wf = W flipped on both shift axes).
+//   The output-channel dimension C is tiny, so the GEMM is turned around: for every row r of the shift plane
+//       D_r[a][t] = sum_{(m,b)} Wf[m][c][a][b] * H[m][r][t + b]          (16x16x4 MFMA: rows a, cols 16 pixels t)
+//   and R[c][y][t] = sum_a D_{y+a}[a][t] is a "col2im" along the row axis.  A wave owns 16 output columns and sweeps
+//   r = 0 .. Dy+3+4*gmax in order, so the col2im never crosses lanes of different t:
+//     lane group g = lane>>4 holds rows a = 4g+q (q = 0..3) of D_r.  A 3-register rolling window per channel sums
+//     q = 0..3 over four consecutive r; the finished group partial P_g(y), y = r-3-4g, is added to a 16-slot LDS ring
+//     (one wave, program order: deterministic); after the last group (gmax = (Ay-1)/4) the row y = r-3-4*gmax is
+//     complete, is stored and its slot cleared.  Utilisation of the 16 MFMA rows is Ay/16.
+//   One workgroup = 4 waves = 64 output columns of one sample, CB channels; H rows are staged RC_RBK at a time for an
+//   atom chunk of MB atoms (zero beyond Hy/Hx/M), Wf for the chunk as [c][k = (m,b)][16 rows], b padded to 4.
+// ================================================================================================================
+constexpr int RC_RBK = 4;
+
+template <int CB>
+__global__ __launch_bounds__(kBlock) void k_mfma_reconstruct(Geo g, int MB, int xblocks, int cgroups,
+                                                             const float *__restrict__ W,
+                                                             const float *__restrict__ H, float *__restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Axp4 = (g.Ax + 3) & ~3;
+    const int HST = 64 + Axp4;
+    const int K4 = MB * Axp4;
+    float *Wl = smem;                          // [CB][K4][16]
+    float *Hs = Wl + CB * K4 * 16;             // [MB][RC_RBK][HST]
+    float *ring = Hs + MB * RC_RBK * HST;      // [4 waves][CB][16 slots][16 cols]
+
+    unsigned bid = blockIdx.x;
+    const int xb = bid % xblocks;
+    bid /= xblocks;
+    const int cg = bid % cgroups;
+    const int n = bid / cgroups;
+    const int c0 = cg * CB, x0 = xb * 64;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int gmax = (g.Ay - 1) >> 2;
+    const int nA = g.Ay * g.Ax;
+    const int nchunks = (g.M + MB - 1) / MB;
+    const int rows_total = g.Dy + 3 + 4 * gmax;
+
+    for (int i = threadIdx.x; i < 4 * CB * 256; i += kBlock) ring[i] = 0.f;
+
+    float w0[CB], w1[CB], w2[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) w0[c] = w1[c] = w2[c] = 0.f;
+
+    for (int rb0 = 0; rb0 < rows_total; rb0 += RC_RBK) {
+        f32x4 acc[RC_RBK][CB];
+#pragma unroll
+        for (int rr = 0; rr < RC_RBK; ++rr)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) acc[rr][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int m0 = ch * MB;
+            __syncthreads();
+            if (nchunks > 1 || rb0 == 0) {
+                for (int i = threadIdx.x; i < CB * K4 * 16; i += kBlock) {
+                    const int a = i & 15;
+                    const int k = (i >> 4) % K4;
+                    const int cc = i / (16 * K4);
+                    const int ml = k / Axp4, b = k - ml * Axp4;
+                    const int m = m0 + ml, c = c0 + cc;
+                    const bool ok = a < g.Ay && b < g.Ax && m < g.M && c < g.C;
+                    Wl[i] = ok ? W[((size_t)m * g.C + c) * nA + (g.Ay - 1 - a) * g.Ax + (g.Ax - 1 - b)] : 0.f;
+                }
+            }
+            for (int i = threadIdx.x; i < MB * RC_RBK * HST; i += kBlock) {
+                const int col = i % HST;
+                const int row = (i / HST) % RC_RBK;
+                const int ml = i / (HST * RC_RBK);
+                const int r = rb0 + row, t = x0 + col, m = m0 + ml;
+                const bool ok = m < g.M && r < g.Hy && t < g.Hx;
+                Hs[i] = ok ? H[(((size_t)n * g.M + m) * g.Hy + r) * g.Hx + t] : 0.f;
+            }
+            __syncthreads();
+
+            const float *wl = Wl + kq * 16 + j;
+            const float *hb = Hs + wave * 16 + j + kq;
+            for (int ml = 0; ml < MB; ++ml) {
+                const float *hm = hb + ml * RC_RBK * HST;
+                const float *wm = wl + ml * Axp4 * 16;
+                for (int b0 = 0; b0 < Axp4; b0 += 4) {
+                    float av[CB];
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) av[c] = wm[(c * K4 + b0) * 16];
+#pragma unroll
+                    for (int rr = 0; rr < RC_RBK; ++rr) {
+                        const float bv = hm[rr * HST + b0];
+#pragma unroll
+                        for (int c = 0; c < CB; ++c) acc[rr][c] = mfma16(av[c], bv, acc[rr][c]);
+                    }
+                }
+            }
+        }
+
+        // col2im along the row axis, rows of this block in order (wave-private: no workgroup barrier needed)
+#pragma unroll
+        for (int rr = 0; rr < RC_RBK; ++rr) {
+            const int r = rb0 + rr;
+            const int y = r - 3 - 4 * kq;
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const f32x4 d = acc[rr][c];
+                const float emit = w2[c] + d[3];
+                w2[c] = w1[c] + d[2];
+                w1[c] = w0[c] + d[1];
+                w0[c] = d[0];
+                if (kq <= gmax) {
+                    float *rp = ring + ((wave * CB + c) * 16 + ((y + 64) & 15)) * 16 + j;
+                    *rp += emit;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int yd = r - 3 - 4 * gmax;
+            const int cc = lane >> 4;
+            if (cc < CB) {
+                float *rp = ring + ((wave * CB + cc) * 16 + ((yd + 64) & 15)) * 16 + j;
+                const float val = *rp;
+                *rp = 0.f;
+                const int x = x0 + wave * 16 + j;
+                if (yd >= 0 && yd < g.Dy && x < g.Dx && c0 + cc < g.C)
+                    R[(((size_t)n * g.C + c0 + cc) * g.Dy + yd) * g.Dx + x] = val;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+struct ReconPlan {
+    int CB, cgroups, xblocks, MB;
+    size_t lds;
+};
+
+ReconPlan plan_reconstruct(const Geo &g) {
+    ReconPlan pl;
+    pl.CB = g.C < 4 ? g.C : 4;
+    pl.cgroups = cdiv(g.C, pl.CB);
+    pl.xblocks = cdiv(g.Dx, 64);
+    const int Axp4 = (g.Ax + 3) & ~3;
+    const int HST = 64 + Axp4;
+    const size_t ring = (size_t)4 * pl.CB * 256 * sizeof(float);
+    const size_t per_atom = ((size_t)pl.CB * Axp4 * 16 + (size_t)RC_RBK * HST) * sizeof(float);
+    const size_t budget = 72 * 1024;
+    long MB = (long)((budget - ring) / per_atom);
+    if (MB > 32) MB = 32;
+    if (MB > g.M) MB = g.M;
+    if (MB < 1) MB = 1;
+    pl.MB = (int)MB;
+    pl.lds = ring + per_atom * pl.MB;
+    return pl;
+}
+
+struct CorrHPlan {
+    int NT, JG, MT, rblocks, cblocks, P;
+    size_t lds;
+};
+
+CorrHPlan plan_corr_H(const tnmf_hip_ctx *ctx, const Geo &g) {
+    CorrHPlan pl;
+    const int J = g.C * g.Ay * g.Ax;
+    const int tiles = cdiv(J, 32);
+    pl.JG = cdiv(tiles, 5);
+    pl.NT = cdiv(tiles, pl.JG);
+    pl.MT = cdiv(g.M, 32);
+    pl.rblocks = cdiv(g.Hy, CH_RH);
+    pl.cblocks = cdiv(g.Hx, CH_TW);
+    const long items = (long)g.N * pl.rblocks * pl.cblocks;
+    long P = (2L * ctx->num_cu) / ((long)pl.MT * pl.JG);
+    if (P < 1) P = 1;
+    // keep one f32 accumulation chain below ~32K terms (K per block = items/P * CH_TW per wave)
+    const long minP = (items * CH_TW + 32767) / 32768;
+    if (P < minP) P = minP;
+    if (P > items) P = items;
+    if (P > 8192) P = 8192;
+    pl.P = (int)P;
+    const size_t stage = ((size_t)32 * CH_AST + 2 * (size_t)g.C * (CH_RH + g.Ay - 1) * (CH_TW + g.Ax) + 8) * sizeof(float);
+    const size_t red = (size_t)4 * 2 * 16 * 64 * sizeof(float);
+    pl.lds = stage > red ? stage : red;
+    return pl;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static bool mfma_common(const Geo &g, int dtype) {
+    if (dtype != 0) return false;
+    if (g.Dy == 1 || g.Ay == 1) return false;   // 1-D signals run on the generic kernels
+    if (g.Ax > 32 || g.Ay > 32) return false;
+    return true;
+}
+
+bool mfma_has_reconstruct(const Geo &g, int dtype) {
+    if (!mfma_common(g, dtype)) return false;
+    return g.Ay >= 3 && g.Ay <= 16;   // rows of the 16x16 tile = atom rows (utilisation Ay/16)
+}
+
+bool mfma_has_corr_W(const Geo &g, int dtype) {
+    if (!mfma_common(g, dtype)) return false;
+    const size_t lds_w = ((size_t)2 * (CW_TY + g.Ay - 1) * CW_XSTR + (size_t)g.Ay * ((g.Ax + 1) & ~1) * 32) * sizeof(float);
+    return lds_w <= 64 * 1024;
+}
+
+bool mfma_has_corr_H(const Geo &g, int dtype) {
+    if (!mfma_common(g, dtype)) return false;
+    tnmf_hip_ctx fake{};
+    fake.num_cu = 256;
+    const CorrHPlan pl = plan_corr_H(&fake, g);
+    return pl.lds <= 64 * 1024 && pl.NT <= 5;
+}
+
+int mfma_reconstruct(tnmf_hip_ctx *, const Geo &g, const float *W, const float *H, float *R, hipStream_t s) {
+    const ReconPlan pl = plan_reconstruct(g);
+    const size_t blocks = (size_t)g.N * pl.cgroups * pl.xblocks;
+    if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
+#define LAUNCH_RC(CB_)                                                                                             \
+    do {                                                                                                           \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_mfma_reconstruct<CB_>,                                \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((k_mfma_reconstruct<CB_>), dim3((unsigned)blocks), dim3(kBlock), pl.lds, s, g, pl.MB,   \
+                           pl.xblocks, pl.cgroups, W, H, R);                                                       \
+    } while (0)
+    switch (pl.CB) {
+        case 1: LAUNCH_RC(1); break;
+        case 2: LAUNCH_RC(2); break;
+        case 3: LAUNCH_RC(3); break;
+        default: LAUNCH_RC(4); break;
+    }
+#undef LAUNCH_RC
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int mfma_corr_W(tnmf_hip_ctx *, const Geo &g, const float *V, const float *R, const float *W, float *H_inout,
+                float *neg, float *pos, bool fused, float reg, hipStream_t s) {
+    const int tiles_y = cdiv(g.Hy, CW_TY), tiles_x = cdiv(g.Hx, CW_TX), MT = cdiv(g.M, 32);
+    const size_t lds = ((size_t)2 * (CW_TY + g.Ay - 1) * CW_XSTR + (size_t)g.Ay * ((g.Ax + 1) & ~1) * 32) * sizeof(float);
+    const size_t blocks = (size_t)g.N * MT * tiles_y * tiles_x;
+    if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
+    if (fused)
+        hipLaunchKernelGGL((k_mfma_corr_W<true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, g, tiles_y, tiles_x, MT,
+                           V, R, W, H_inout, (float *)nullptr, (float *)nullptr, reg);
+    else
+        hipLaunchKernelGGL((k_mfma_corr_W<false>), dim3((unsigned)blocks), dim3(kBlock), lds, s, g, tiles_y, tiles_x,
+                           MT, V, R, W, (float *)nullptr, neg, pos, 0.f);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int mfma_corr_H_chunks(const tnmf_hip_ctx *ctx, const Geo &g) {
+    if (!mfma_has_corr_H(g, 0)) return 0;
+    return plan_corr_H(ctx, g).P;
+}
+
+int mfma_corr_H(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *H, double *partials,
+                int P, hipStream_t s) {
+    const CorrHPlan pl = plan_corr_H(ctx, g);
+    if (P != pl.P) return TNMF_E_WORKSPACE;
+    const dim3 grid(pl.P, pl.MT, pl.JG);
+#define LAUNCH_CH(NT_)                                                                                             \
+    hipLaunchKernelGGL((k_mfma_corr_H<NT_>), grid, dim3(kBlock), pl.lds, s, g, pl.P, pl.rblocks, pl.cblocks, V, R, H, \
+                       partials)
+    switch (pl.NT) {
+        case 1: LAUNCH_CH(1); break;
+        case 2: LAUNCH_CH(2); break;
+        case 3: LAUNCH_CH(3); break;
+        case 4: LAUNCH_CH(4); break;
+        case 5: LAUNCH_CH(5); break;
+        default: return TNMF_E_UNSUPPORTED;
+    }
+#undef LAUNCH_CH
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
 }
