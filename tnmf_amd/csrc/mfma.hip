@@ -42,7 +42,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 constexpr int CW_TY = 16, CW_TX = 32, CW_RB = 4, CW_XSTR = 64;
 
 template <bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_mfma_corr_W(Geo g, int tiles_y, int tiles_x, int MT,
+__global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, int tiles_x, int MT,
                                                         const float *__restrict__ V, const float *__restrict__ Rr,
                                                         const float *__restrict__ W, float *__restrict__ Hio,
                                                         float *__restrict__ neg, float *__restrict__ pos, float reg) {
@@ -95,22 +95,54 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_W(Geo g, int tiles_y, int 
         }
         __syncthreads();
 
+        // flattened k loop over (a, b-pair), unrolled by two with two operand register sets: the LDS reads of step
+        // st+1 are issued before the MFMAs of step st, so the matrix pipe never waits on LDS latency
         const float *vb = Vs + (wave * CW_RB) * CW_XSTR + j + h;
         const float *rb_ = Rs + (wave * CW_RB) * CW_XSTR + j + h;
         const float *wb = Ws + h * 32 + j;
-        for (int a = 0; a < g.Ay; ++a) {
-            const float *va = vb + a * CW_XSTR;
-            const float *ra = rb_ + a * CW_XSTR;
-            const float *wa = wb + a * Axp * 32;
-            for (int b2 = 0; b2 < Axp; b2 += 2) {
-                const float wv = wa[b2 * 32];
-#pragma unroll
-                for (int rb = 0; rb < CW_RB; ++rb) {
-                    an[rb] = mfma32(wv, va[rb * CW_XSTR + b2], an[rb]);
-                    ap[rb] = mfma32(wv, ra[rb * CW_XSTR + b2], ap[rb]);
-                }
-            }
+        const int nsteps = g.Ay * (Axp >> 1);
+        int b2 = 0, xo = 0, st = 0;
+        float wA, vA[CW_RB], rA[CW_RB], wB, vB[CW_RB], rB[CW_RB];
+#define CW_LOAD(w_, v_, r_)                                   \
+    do {                                                      \
+        w_ = wb[st * 64];                                     \
+        _Pragma("unroll") for (int rb = 0; rb < CW_RB; ++rb) { \
+            v_[rb] = vb[rb * CW_XSTR + xo];                   \
+            r_[rb] = rb_[rb * CW_XSTR + xo];                  \
+        }                                                     \
+    } while (0)
+#define CW_NEXT()                  \
+    do {                           \
+        ++st;                      \
+        b2 += 2;                   \
+        xo += 2;                   \
+        if (b2 == Axp) {           \
+            b2 = 0;                \
+            xo += CW_XSTR - Axp;   \
+        }                          \
+    } while (0)
+#define CW_MMA(w_, v_, r_)                                    \
+    do {                                                      \
+        _Pragma("unroll") for (int rb = 0; rb < CW_RB; ++rb) { \
+            an[rb] = mfma32(w_, v_[rb], an[rb]);              \
+            ap[rb] = mfma32(w_, r_[rb], ap[rb]);              \
+        }                                                     \
+    } while (0)
+        CW_LOAD(wA, vA, rA);
+        while (st + 2 <= nsteps) {
+            CW_NEXT();
+            CW_LOAD(wB, vB, rB);
+            __builtin_amdgcn_sched_barrier(0);
+            CW_MMA(wA, vA, rA);
+            CW_NEXT();
+            if (st < nsteps) CW_LOAD(wA, vA, rA);
+            __builtin_amdgcn_sched_barrier(0);
+            CW_MMA(wB, vB, rB);
         }
+        if (st < nsteps) CW_MMA(wA, vA, rA);
+#undef CW_LOAD
+#undef CW_NEXT
+#undef CW_MMA
     }
 
     const int vv = v0 + j;
@@ -146,20 +178,20 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_W(Geo g, int tiles_y, int 
 //   32 columns of one MFMA (consecutive J) read 32 consecutive LDS words.
 //   Output: partials[p][m*C + c][s = a'*Ax + b'][{V, R}] in double (summed in fixed order by k_corr_H_finalize).
 // ================================================================================================================
-constexpr int CH_RH = 4, CH_TW = 64, CH_AST = CH_RH * CH_TW + 1;
+constexpr int CH_RH = 4, CH_TW = 64, CH_AST = CH_RH * CH_TW + 1, CH_ZL = CH_TW + 8;
 
 template <int NT>
-__global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, int P, int rblocks, int cblocks,
-                                                        const float *__restrict__ V, const float *__restrict__ Rr,
-                                                        const float *__restrict__ H, double *__restrict__ partials) {
+__global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, int P, int rblocks, int cblocks,
+                                                           const float *__restrict__ V, const float *__restrict__ Rr,
+                                                           const float *__restrict__ H, double *__restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int XST = CH_TW + g.Ax;
     const int XR = CH_RH + g.Ay - 1;
-    const int plane = XR * XST;          // one channel of one of V / R
-    float *Hs = smem;                    // [32][CH_AST]
-    float *Xv = Hs + 32 * CH_AST;        // [C][XR][XST]
-    float *Xr = Xv + g.C * plane;        // [C][XR][XST]
-    float *zero = Xr + g.C * plane;      // one zero word (+pad): target of out-of-range columns
+    const int plane = XR * XST;              // one channel of one of V / R
+    const int RS = g.C * plane + CH_ZL;      // distance from the V windows to the R windows
+    float *Hs = smem;                        // [32][CH_AST]
+    float *Xv = Hs + 32 * CH_AST;            // [C][XR][XST] then CH_ZL zeros
+    float *Xr = Xv + RS;                     // [C][XR][XST] then CH_ZL zeros
 
     const int p = blockIdx.x, mt = blockIdx.y, jg = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,17 +199,18 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, int P, int rblock
     const int nA = g.Ay * g.Ax;
     const int J = g.C * nA;
 
-    // per-lane B-operand base (in floats, relative to Xv / Xr) for each of the NT column tiles; -1 => zero word
-    int boff[NT];
+    // per-lane B-operand offset (floats, relative to Xv) of each of the NT column tiles; columns beyond J walk
+    // through the zero strip behind the windows, so every lane advances by the same k offset
+    int bo[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = (jg * NT + t) * 32 + j;
         if (col < J) {
             const int c = col / nA, s = col - c * nA;
             const int a = s / g.Ax, b = s - a * g.Ax;
-            boff[t] = c * plane + (wave + (g.Ay - 1) - a) * XST + (g.Ax - 1) - b + h;
+            bo[t] = c * plane + (wave + (g.Ay - 1) - a) * XST + (g.Ax - 1) - b + h;
         } else {
-            boff[t] = -1;
+            bo[t] = g.C * plane;
         }
     }
 
@@ -187,7 +220,10 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, int P, int rblock
         accv[t] = zero16();
         accr[t] = zero16();
     }
-    if (threadIdx.x < 8) zero[threadIdx.x] = 0.f;
+    for (int i = threadIdx.x; i < CH_ZL; i += kBlock) {
+        Xv[g.C * plane + i] = 0.f;
+        Xr[g.C * plane + i] = 0.f;
+    }
 
     const int items = g.N * rblocks * cblocks;
     for (int it = p; it < items; it += P) {
@@ -221,17 +257,35 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, int P, int rblock
         }
         __syncthreads();
 
+        // k loop over the CH_TW pixels of this wave's row, two per MFMA, unrolled by two with two operand sets
         const float *ha = Hs + j * CH_AST + wave * CH_TW + h;
-        for (int k2 = 0; k2 < CH_TW; k2 += 2) {
-            const float hv = ha[k2];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float *bv = boff[t] >= 0 ? Xv + boff[t] + k2 : zero;
-                const float *br = boff[t] >= 0 ? Xr + boff[t] + k2 : zero;
-                accv[t] = mfma32(hv, *bv, accv[t]);
-                accr[t] = mfma32(hv, *br, accr[t]);
-            }
+        float hA, vA[NT], rA[NT], hB, vB[NT], rB[NT];
+#define CH_LOAD(h_, v_, r_, K2)                                         \
+    do {                                                                \
+        h_ = ha[K2];                                                    \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                \
+            v_[t] = Xv[bo[t] + (K2)];                                   \
+            r_[t] = Xr[bo[t] + (K2)];                                   \
+        }                                                               \
+    } while (0)
+#define CH_MMA(h_, v_, r_)                                              \
+    do {                                                                \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                \
+            accv[t] = mfma32(h_, v_[t], accv[t]);                       \
+            accr[t] = mfma32(h_, r_[t], accr[t]);                       \
+        }                                                               \
+    } while (0)
+        CH_LOAD(hA, vA, rA, 0);
+        for (int k2 = 0; k2 < CH_TW; k2 += 4) {
+            CH_LOAD(hB, vB, rB, k2 + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            CH_MMA(hA, vA, rA);
+            if (k2 + 4 < CH_TW) CH_LOAD(hA, vA, rA, k2 + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            CH_MMA(hB, vB, rB);
         }
+#undef CH_LOAD
+#undef CH_MMA
     }
 
     // fold the 4 waves (they split K) through LDS in fixed order, then write this block's partial in double
@@ -342,23 +396,50 @@ __global__ __launch_bounds__(kBlock) void k_mfma_reconstruct(Geo g, int MB, int 
             }
             __syncthreads();
 
+            // flattened k loop over (atom, b-quad): A offsets are linear in the step, B offsets wrap per atom;
+            // unrolled by two with two operand register sets (LDS reads of step st+1 fly under the MFMAs of step st)
             const float *wl = Wl + kq * 16 + j;
             const float *hb = Hs + wave * 16 + j + kq;
-            for (int ml = 0; ml < MB; ++ml) {
-                const float *hm = hb + ml * RC_RBK * HST;
-                const float *wm = wl + ml * Axp4 * 16;
-                for (int b0 = 0; b0 < Axp4; b0 += 4) {
-                    float av[CB];
-#pragma unroll
-                    for (int c = 0; c < CB; ++c) av[c] = wm[(c * K4 + b0) * 16];
-#pragma unroll
-                    for (int rr = 0; rr < RC_RBK; ++rr) {
-                        const float bv = hm[rr * HST + b0];
-#pragma unroll
-                        for (int c = 0; c < CB; ++c) acc[rr][c] = mfma16(av[c], bv, acc[rr][c]);
-                    }
-                }
+            const int nb = Axp4 >> 2;
+            const int nsteps = MB * nb;
+            int bq = 0, ho = 0, st = 0;
+            float aA[CB], bA[RC_RBK], aB[CB], bB[RC_RBK];
+#define RC_LOAD(a_, b_)                                                                     \
+    do {                                                                                    \
+        _Pragma("unroll") for (int c = 0; c < CB; ++c) a_[c] = wl[(c * K4 + st * 4) * 16];  \
+        _Pragma("unroll") for (int rr = 0; rr < RC_RBK; ++rr) b_[rr] = hb[rr * HST + ho];   \
+    } while (0)
+#define RC_NEXT()                           \
+    do {                                    \
+        ++st;                               \
+        ++bq;                               \
+        ho += 4;                            \
+        if (bq == nb) {                     \
+            bq = 0;                         \
+            ho += RC_RBK * HST - Axp4;      \
+        }                                   \
+    } while (0)
+#define RC_MMA(a_, b_)                                                                      \
+    do {                                                                                    \
+        _Pragma("unroll") for (int rr = 0; rr < RC_RBK; ++rr)                               \
+            _Pragma("unroll") for (int c = 0; c < CB; ++c)                                  \
+                acc[rr][c] = mfma16(a_[c], b_[rr], acc[rr][c]);                             \
+    } while (0)
+            RC_LOAD(aA, bA);
+            while (st + 2 <= nsteps) {
+                RC_NEXT();
+                RC_LOAD(aB, bB);
+                __builtin_amdgcn_sched_barrier(0);
+                RC_MMA(aA, bA);
+                RC_NEXT();
+                if (st < nsteps) RC_LOAD(aA, bA);
+                __builtin_amdgcn_sched_barrier(0);
+                RC_MMA(aB, bB);
             }
+            if (st < nsteps) RC_MMA(aA, bA);
+#undef RC_LOAD
+#undef RC_NEXT
+#undef RC_MMA
         }
 
         // col2im along the row axis, rows of this block in order (wave-private: no workgroup barrier needed)
@@ -441,7 +522,7 @@ CorrHPlan plan_corr_H(const tnmf_hip_ctx *ctx, const Geo &g) {
     if (P > items) P = items;
     if (P > 8192) P = 8192;
     pl.P = (int)P;
-    const size_t stage = ((size_t)32 * CH_AST + 2 * (size_t)g.C * (CH_RH + g.Ay - 1) * (CH_TW + g.Ax) + 8) * sizeof(float);
+    const size_t stage = ((size_t)32 * CH_AST + 2 * ((size_t)g.C * (CH_RH + g.Ay - 1) * (CH_TW + g.Ax) + CH_ZL)) * sizeof(float);
     const size_t red = (size_t)4 * 2 * 16 * 64 * sizeof(float);
     pl.lds = stage > red ? stage : red;
     return pl;
