@@ -145,23 +145,36 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
 #undef CW_MMA
     }
 
+    // epilogue.  Lane (j, h) holds pixel column v0+j of 16 atoms per accumulator: for a fixed register the 32 lanes of a
+    // half write 128 contiguous bytes.  The H values of one tile row are all loaded before the first store so that the
+    // 16 loads are independent (one memory round trip per row, not one per element).
     const int vv = v0 + j;
     if (vv < g.Hx) {
+        const size_t mstride = (size_t)g.Hy * g.Hx;
 #pragma unroll
         for (int rb = 0; rb < CW_RB; ++rb) {
             const int u = u0 + wave * CW_RB + rb;
             if (u < g.Hy) {
+                const size_t base = (((size_t)n * g.M + mt * 32 + 4 * h) * g.Hy + u) * g.Hx + vv;
+                if (FUSED) {
+                    float hv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < g.M) {
-                        const size_t o = (((size_t)n * g.M + m) * g.Hy + u) * g.Hx + vv;
-                        if (FUSED) {
-                            const float hv = Hio[o];
-                            Hio[o] = (hv * an[rb][r]) / (ap[rb][r] + reg);
-                        } else {
-                            neg[o] = an[rb][r];
-                            pos[o] = ap[rb][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = (r & 3) + 8 * (r >> 2);
+                        hv[r] = (mt * 32 + 4 * h + ml < g.M) ? Hio[base + ml * mstride] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = (r & 3) + 8 * (r >> 2);
+                        if (mt * 32 + 4 * h + ml < g.M) Hio[base + ml * mstride] = (hv[r] * an[rb][r]) / (ap[rb][r] + reg);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = (r & 3) + 8 * (r >> 2);
+                        if (mt * 32 + 4 * h + ml < g.M) {
+                            neg[base + ml * mstride] = an[rb][r];
+                            pos[base + ml * mstride] = ap[rb][r];
                         }
                     }
                 }
@@ -332,11 +345,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, int P, int rbl
 //   atom chunk of MB atoms (zero beyond Hy/Hx/M), Wf for the chunk as [c][k = (m,b)][16 rows], b padded to 4.
 // ================================================================================================================
 constexpr int RC_RBK = 4;
+constexpr int RC_MAXLPW = 32;    // (atom, row) lines staged per wave: MB * RC_RBK / 4 <= 32
+constexpr int RC_MAXTAIL = 16;   // packed tail loads per wave (tail = columns 64 .. 64+Axp4-1 of a line)
 
 template <int CB>
-__global__ __launch_bounds__(kBlock) void k_mfma_reconstruct(Geo g, int MB, int xblocks, int cgroups,
-                                                             const float *__restrict__ W,
-                                                             const float *__restrict__ H, float *__restrict__ R) {
+__global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, int xblocks, int cgroups,
+                                                                const float *__restrict__ W,
+                                                                const float *__restrict__ H, float *__restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Axp4 = (g.Ax + 3) & ~3;
     const int HST = 64 + Axp4;
@@ -358,6 +373,52 @@ __global__ __launch_bounds__(kBlock) void k_mfma_reconstruct(Geo g, int MB, int 
     const int nA = g.Ay * g.Ax;
     const int nchunks = (g.M + MB - 1) / MB;
     const int rows_total = g.Dy + 3 + 4 * gmax;
+    const int nrb = (rows_total + RC_RBK - 1) / RC_RBK;
+    const int nstages = nrb * nchunks;
+
+    // ---- staging map of this thread (fixed over the sweep).  Lines = (atom ml, row) pairs, line = ml*RC_RBK + row;
+    // wave w stages lines w, w+4, ...: columns 0..63 one per lane ("main"), columns 64..HST-1 packed lpi lines per
+    // instruction ("tail").  The values of stage s+1 are fetched into registers while stage s is being multiplied.
+    const int nlines = MB * RC_RBK;
+    const int lpw = (nlines + 3) >> 2;
+    const int lpi = 64 / Axp4;                       // lines per tail instruction
+    const int ntail = (lpw + lpi - 1) / lpi;
+    const int tl = lane / Axp4, tc = lane - tl * Axp4;
+    const bool main_ok = x0 + lane < g.Hx;
+    const bool tail_ok = tl < lpi && x0 + 64 + tc < g.Hx;
+    const float *Hn = H + (size_t)n * g.M * g.Hy * g.Hx + x0;
+    float pm[RC_MAXLPW], pt[RC_MAXTAIL];
+
+    auto prefetch = [&](int stage) {
+        const int rb0 = (stage / nchunks) * RC_RBK;
+        const int m0 = (stage % nchunks) * MB;
+#pragma unroll
+        for (int q = 0; q < RC_MAXLPW; ++q) {
+            const int line = wave + 4 * q;
+            const int m = m0 + (line >> 2), r = rb0 + (line & 3);
+            const bool ok = q < lpw && line < nlines && m < g.M && r < g.Hy && main_ok;
+            pm[q] = ok ? Hn[((size_t)m * g.Hy + r) * g.Hx + lane] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < RC_MAXTAIL; ++i) {
+            const int line = wave + 4 * (i * lpi + tl);
+            const int m = m0 + (line >> 2), r = rb0 + (line & 3);
+            const bool ok = i < ntail && i * lpi + tl < lpw && line < nlines && m < g.M && r < g.Hy && tail_ok;
+            pt[i] = ok ? Hn[((size_t)m * g.Hy + r) * g.Hx + 64 + tc] : 0.f;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < RC_MAXLPW; ++q) {
+            const int line = wave + 4 * q;
+            if (q < lpw && line < nlines) Hs[line * HST + lane] = pm[q];
+        }
+#pragma unroll
+        for (int i = 0; i < RC_MAXTAIL; ++i) {
+            const int line = wave + 4 * (i * lpi + tl);
+            if (i < ntail && tl < lpi && i * lpi + tl < lpw && line < nlines) Hs[line * HST + 64 + tc] = pt[i];
+        }
+    };
 
     for (int i = threadIdx.x; i < 4 * CB * 256; i += kBlock) ring[i] = 0.f;
 
@@ -365,6 +426,8 @@ __global__ __launch_bounds__(kBlock) void k_mfma_reconstruct(Geo g, int MB, int 
 #pragma unroll
     for (int c = 0; c < CB; ++c) w0[c] = w1[c] = w2[c] = 0.f;
 
+    prefetch(0);
+    int stage = 0;
     for (int rb0 = 0; rb0 < rows_total; rb0 += RC_RBK) {
         f32x4 acc[RC_RBK][CB];
 #pragma unroll
@@ -372,9 +435,9 @@ __global__ __launch_bounds__(kBlock) void k_mfma_reconstruct(Geo g, int MB, int 
 #pragma unroll
             for (int c = 0; c < CB; ++c) acc[rr][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int ch = 0; ch < nchunks; ++ch) {
+        for (int ch = 0; ch < nchunks; ++ch, ++stage) {
             const int m0 = ch * MB;
-            __syncthreads();
+            __syncthreads();   // every wave is done with the previous stage's tile
             if (nchunks > 1 || rb0 == 0) {
                 for (int i = threadIdx.x; i < CB * K4 * 16; i += kBlock) {
                     const int a = i & 15;
@@ -386,15 +449,9 @@ __global__ __launch_bounds__(kBlock) void k_mfma_reconstruct(Geo g, int MB, int 
                     Wl[i] = ok ? W[((size_t)m * g.C + c) * nA + (g.Ay - 1 - a) * g.Ax + (g.Ax - 1 - b)] : 0.f;
                 }
             }
-            for (int i = threadIdx.x; i < MB * RC_RBK * HST; i += kBlock) {
-                const int col = i % HST;
-                const int row = (i / HST) % RC_RBK;
-                const int ml = i / (HST * RC_RBK);
-                const int r = rb0 + row, t = x0 + col, m = m0 + ml;
-                const bool ok = m < g.M && r < g.Hy && t < g.Hx;
-                Hs[i] = ok ? H[(((size_t)n * g.M + m) * g.Hy + r) * g.Hx + t] : 0.f;
-            }
+            commit();
             __syncthreads();
+            if (stage + 1 < nstages) prefetch(stage + 1);   // in flight under the MFMAs below
 
             // flattened k loop over (atom, b-quad): A offsets are linear in the step, B offsets wrap per atom;
             // unrolled by two with two operand register sets (LDS reads of step st+1 fly under the MFMAs of step st)
@@ -442,7 +499,9 @@ __global__ __launch_bounds__(kBlock) void k_mfma_reconstruct(Geo g, int MB, int 
 #undef RC_MMA
         }
 
-        // col2im along the row axis, rows of this block in order (wave-private: no workgroup barrier needed)
+        // col2im along the row axis, rows of this block in order.  The ring is private to the wave and LDS operations
+        // of one wave execute in program order, so the accumulate (ds_add_f32, no return) needs no wait before the
+        // read of the finished row; only the compiler has to be kept from reordering them.
 #pragma unroll
         for (int rr = 0; rr < RC_RBK; ++rr) {
             const int r = rb0 + rr;
@@ -456,21 +515,20 @@ __global__ __launch_bounds__(kBlock) void k_mfma_reconstruct(Geo g, int MB, int 
                 w0[c] = d[0];
                 if (kq <= gmax) {
                     float *rp = ring + ((wave * CB + c) * 16 + ((y + 64) & 15)) * 16 + j;
-                    *rp += emit;
+                    __hip_atomic_fetch_add(rp, emit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
             const int yd = r - 3 - 4 * gmax;
             const int cc = lane >> 4;
             if (cc < CB) {
                 float *rp = ring + ((wave * CB + cc) * 16 + ((yd + 64) & 15)) * 16 + j;
-                const float val = *rp;
-                *rp = 0.f;
+                const float val = __hip_atomic_exchange(rp, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 const int x = x0 + wave * 16 + j;
                 if (yd >= 0 && yd < g.Dy && x < g.Dx && c0 + cc < g.C)
                     R[(((size_t)n * g.C + c0 + cc) * g.Dy + yd) * g.Dx + x] = val;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
         }
     }
 }
