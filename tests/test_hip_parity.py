@@ -227,6 +227,27 @@ def test_f32_loop_parity_with_f64_oracle(N, C, D, M, A, path):
     assert abs(nmf._energy_function() - ref.energy()) / ref.energy() < 1e-5
 
 
+def test_matrix_core_kernels_are_dispatched():
+    """The float32 2-D shapes of the BASELINE configs must run on the MFMA kernels, not fall back silently."""
+    for (C, M, A) in ((1, 16, (9, 9)), (1, 32, (12, 12)), (3, 32, (12, 12)), (3, 64, (16, 16))):
+        rng = np.random.default_rng(0)
+        D = (40, 72)
+        V = rng.random((2, C) + D).astype(np.float32)
+        be = make_backend(V, A, M, 'mfma')        # 'mfma' = no generic fallback: unsupported shapes raise
+        W = dev(rng.random((M, C) + A), np.float32)
+        H = dev(rng.random((2, M) + tuple(d + a - 1 for d, a in zip(D, A))), np.float32)
+        R = be.reconstruct(W, H)
+        assert be.last_path == 'mfma'
+        be.reconstruction_gradient_H(V, W, H)
+        assert be.last_path == 'mfma'
+        neg, pos = be.reconstruction_gradient_W(V, W, H)
+        assert be.last_path == 'mfma'
+        Wn, Hn = be.to_ndarray(W).astype(np.float64), be.to_ndarray(H).astype(np.float64)
+        on, op = orc.gradient_W(V.astype(np.float64), Wn, Hn, slice(None), 'c')
+        assert relmax(be.to_ndarray(neg), on) < 2e-5 and relmax(be.to_ndarray(pos), op) < 2e-5
+        assert relmax(be.to_ndarray(R), orc.reconstruct(Wn, Hn, 'c')) < 2e-5
+
+
 def test_errors_like_the_reference():
     with pytest.raises(NotImplementedError):
         HIP_Backend(reconstruction_mode='full')                   # NumPy.py:26-27 precedent

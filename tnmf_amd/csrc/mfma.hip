@@ -63,7 +63,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
     const int n = bid / MT;
     const int u0 = tyi * CW_TY, v0 = txi * CW_TX;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: lives in an SGPR
     const int j = lane & 31, h = lane >> 5;
     const int nA = g.Ay * g.Ax;
     const int need_w = CW_TX + Axp - 1;
@@ -184,147 +185,249 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
 }
 
 // ================================================================================================================
-// corr_H: grid (P, MT, JG).  Work item = (sample n, CH_RH rows x CH_TW cols of the shift plane).  A = the H tile of
-//   32 atoms; B[k = pixel (r,t)][j = column J] = X[c][r - a'][t - b'] with J = c*nA + a'*Ax + b' (zero outside the
-//   sample).  Wave w takes row w of the tile (the waves split K), every wave owns all NT column tiles of its column
-//   group jg for both V and R: 2*NT accumulators of 32x32.  X row stride = CH_TW + Ax, i.e. == Ax (mod 32), so that the
-//   32 columns of one MFMA (consecutive J) read 32 consecutive LDS words.
+// corr_H: grid (P, MT, JG).  Work item = (sample n, CH_RH rows x TW cols of the shift plane), TW chosen to divide
+//   Hx with little padding.  16x16x4 MFMA: A[atom][k = pixel] = H tile, B[k = pixel (r,t)][j = column J] =
+//   X[c][r - a'][t - b'] with J = c*nA + a'*Ax + b' (zero outside the sample; columns beyond J walk a zero strip).
+//   The 4 waves are (atom half ah, row pair kh): wave (ah, kh) multiplies atoms 16*ah..16*ah+15 with rows 2*kh, 2*kh+1
+//   of the tile for all NT 16-column tiles of its column group, for V and for R: 2*NT accumulators of 16x16.
+//   Layout notes: H tile atom stride == 2 (mod 32) and X row stride == Ax (mod 32) make both operand reads
+//   conflict-free (a wave reads 64 consecutive-ish words).  The next item's H tile and X windows are fetched into
+//   registers while the current item is multiplied.
 //   Output: partials[p][m*C + c][s = a'*Ax + b'][{V, R}] in double (summed in fixed order by k_corr_H_finalize).
 // ================================================================================================================
-constexpr int CH_RH = 4, CH_TW = 64, CH_AST = CH_RH * CH_TW + 1, CH_ZL = CH_TW + 8;
+constexpr int CH_RH = 4;
+constexpr int CH_MAXTAIL = 8;   // packed tail loads per wave of the H tile (columns 64 .. TW-1)
+constexpr int CH_XE = 8;        // X-window elements prefetched per thread and array (else staged without prefetch)
+
+struct CorrHGeom {
+    int TW, AST, XSTW, rblocks, cblocks, P;
+};
 
 template <int NT>
-__global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, int P, int rblocks, int cblocks,
-                                                           const float *__restrict__ V, const float *__restrict__ Rr,
+__global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, const float *__restrict__ V,
+                                                           const float *__restrict__ Rr,
                                                            const float *__restrict__ H, double *__restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int XST = CH_TW + g.Ax;
+    const int TW = cg.TW, AST = cg.AST;
+    const int XST = cg.XSTW + g.Ax;
     const int XR = CH_RH + g.Ay - 1;
     const int plane = XR * XST;              // one channel of one of V / R
-    const int RS = g.C * plane + CH_ZL;      // distance from the V windows to the R windows
-    float *Hs = smem;                        // [32][CH_AST]
-    float *Xv = Hs + 32 * CH_AST;            // [C][XR][XST] then CH_ZL zeros
-    float *Xr = Xv + RS;                     // [C][XR][XST] then CH_ZL zeros
+    const int ZL = TW + XST + 8;             // zero strip behind the windows
+    const int RS = g.C * plane + ZL;         // distance from the V windows to the R windows
+    float *Hs = smem;                        // [32][AST]
+    float *Xv = Hs + 32 * AST;               // [C][XR][XST] then ZL zeros
+    float *Xr = Xv + RS;
 
     const int p = blockIdx.x, mt = blockIdx.y, jg = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: lives in an SGPR
+    const int ah = wave >> 1, kh = wave & 1;
+    const int j = lane & 15, kq = lane >> 4;
     const int nA = g.Ay * g.Ax;
     const int J = g.C * nA;
 
-    // per-lane B-operand offset (floats, relative to Xv) of each of the NT column tiles; columns beyond J walk
-    // through the zero strip behind the windows, so every lane advances by the same k offset
     int bo[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int col = (jg * NT + t) * 32 + j;
+        const int col = (jg * NT + t) * 16 + j;
         if (col < J) {
             const int c = col / nA, s = col - c * nA;
             const int a = s / g.Ax, b = s - a * g.Ax;
-            bo[t] = c * plane + (wave + (g.Ay - 1) - a) * XST + (g.Ax - 1) - b + h;
+            bo[t] = c * plane + (2 * kh + (g.Ay - 1) - a) * XST + (g.Ax - 1) - b + kq;
         } else {
             bo[t] = g.C * plane;
         }
     }
 
-    f32x16 accv[NT], accr[NT];
+    f32x4 accv[NT], accr[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        accv[t] = zero16();
-        accr[t] = zero16();
+        accv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int i = threadIdx.x; i < CH_ZL; i += kBlock) {
+    for (int i = threadIdx.x; i < ZL; i += kBlock) {
         Xv[g.C * plane + i] = 0.f;
         Xr[g.C * plane + i] = 0.f;
     }
 
-    const int items = g.N * rblocks * cblocks;
-    for (int it = p; it < items; it += P) {
-        int q = it;
-        const int cbi = q % cblocks;
-        q /= cblocks;
-        const int rbi = q % rblocks;
-        const int n = q / rblocks;
-        const int r0 = rbi * CH_RH, t0 = cbi * CH_TW;
+    // ---- staging map (fixed): H tile lines = (atom mi, row), line = mi*CH_RH + row, 128 lines; wave w stages lines
+    // w, w+4, ...: columns 0..63 one per lane, columns 64..TW-1 packed lpi lines per instruction
+    const int TL = TW > 64 ? TW - 64 : 0;
+    const int lpi = TL ? 64 / TL : 1;
+    const int ntail = TL ? (32 + lpi - 1) / lpi : 0;
+    const int tl = TL ? lane / TL : 0, tc = TL ? lane - tl * TL : 0;
+    const int xelems = g.C * plane;
+    const bool x_pref = xelems <= CH_XE * kBlock;
+    float pm[32], pt[CH_MAXTAIL], pxv[CH_XE], pxr[CH_XE];
 
-        __syncthreads();
-        // H tile: 32 atoms x CH_RH rows x CH_TW cols
-        for (int i = threadIdx.x; i < 32 * CH_RH * CH_TW; i += kBlock) {
-            const int col = i % CH_TW;
-            const int row = (i / CH_TW) % CH_RH;
-            const int mi = i / (CH_TW * CH_RH);
-            const int m = mt * 32 + mi, r = r0 + row, t = t0 + col;
-            const bool in = m < g.M && r < g.Hy && t < g.Hx;
-            Hs[mi * CH_AST + row * CH_TW + col] = in ? H[(((size_t)n * g.M + m) * g.Hy + r) * g.Hx + t] : 0.f;
+    auto item_coords = [&](int it, int &n, int &r0, int &t0) {
+        const int cbi = it % cg.cblocks;
+        it /= cg.cblocks;
+        const int rbi = it % cg.rblocks;
+        n = it / cg.rblocks;
+        r0 = rbi * CH_RH;
+        t0 = cbi * TW;
+    };
+    // X-window element i of an item: returns whether it lies inside the sample; the address is clamped so that the
+    // load itself is always legal (the value is masked when it is written to LDS)
+    auto x_addr = [&](int i, int n, int r0, int t0, size_t &o) -> bool {
+        const int ic = i < xelems ? i : 0;
+        const int c = ic / plane;
+        const int rem = ic - c * plane;
+        const int row = rem / XST, col = rem - row * XST;
+        const int y = r0 - (g.Ay - 1) + row, x = t0 - (g.Ax - 1) + col;
+        const bool in = i < xelems && y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
+        const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1), xc = x < 0 ? 0 : (x < g.Dx ? x : g.Dx - 1);
+        o = (((size_t)n * g.C + c) * g.Dy + yc) * g.Dx + xc;
+        return in;
+    };
+    // line wave + 4q of the tile is (atom q, row wave): one running pointer with the atom stride, which is made
+    // opaque per item so that the compiler recomputes its multiples in the scalar unit instead of keeping them live
+    auto prefetch = [&](int it) {
+        int n, r0, t0;
+        item_coords(it, n, r0, t0);
+        size_t astr = (size_t)g.Hy * g.Hx;
+        asm volatile("" : "+s"(astr));
+        const int r = r0 + wave;
+        const int nat = g.M - mt * 32;   // atoms of this tile that exist (>= 1)
+        // loads are unconditional on clamped (always valid) addresses and zeroed afterwards: no branch per load
+        const int rc = r < g.Hy ? r : g.Hy - 1;
+        const int lc = t0 + lane < g.Hx ? lane : g.Hx - 1 - t0;
+        const int tcc = t0 + 64 + tc < g.Hx ? 64 + tc : g.Hx - 1 - t0;
+        const float *src = H + (((size_t)n * g.M + mt * 32) * g.Hy + rc) * g.Hx + t0;
+        // NB: the raw values stay untouched until commit() masks them, so nothing waits on these loads here
+#pragma unroll
+        for (int q = 0; q < 32; ++q) pm[q] = src[(q < nat ? q : nat - 1) * astr + lc];
+#pragma unroll
+        for (int i = 0; i < CH_MAXTAIL; ++i) {
+            const int q = i * lpi + tl;
+            if (i < ntail) pt[i] = src[(q < nat ? q : nat - 1) * astr + tcc];
         }
-        // zero-padded V and R windows: rows r0-(Ay-1) .. r0+RH-1, cols t0-(Ax-1) .. t0+TW-1 (+1 pad column)
-        for (int i = threadIdx.x; i < g.C * plane; i += kBlock) {
-            const int c = i / plane;
-            const int rem = i - c * plane;
-            const int row = rem / XST, col = rem - row * XST;
-            const int y = r0 - (g.Ay - 1) + row, x = t0 - (g.Ax - 1) + col;
-            const bool in = y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
-            const size_t o = (((size_t)n * g.C + c) * g.Dy + y) * g.Dx + x;
-            Xv[i] = in ? V[o] : 0.f;
-            Xr[i] = in ? Rr[o] : 0.f;
+        if (x_pref) {
+#pragma unroll
+            for (int e = 0; e < CH_XE; ++e) {
+                size_t o;
+                (void)x_addr(threadIdx.x + e * kBlock, n, r0, t0, o);
+                pxv[e] = V[o];
+                pxr[e] = Rr[o];
+            }
         }
-        __syncthreads();
+    };
+    auto commit = [&](int it) {
+        int n_, r0_, t0_;
+        item_coords(it, n_, r0_, t0_);
+        const int nat = g.M - mt * 32;
+        const bool mok = r0_ + wave < g.Hy && t0_ + lane < g.Hx;
+        const bool tok = r0_ + wave < g.Hy && t0_ + 64 + tc < g.Hx;
+        float *dst = Hs + wave * TW;
+#pragma unroll
+        for (int q = 0; q < 32; ++q)
+            if (lane < TW) dst[q * AST + lane] = (mok && q < nat) ? pm[q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < CH_MAXTAIL; ++i) {
+            const int q = i * lpi + tl;
+            if (i < ntail && tl < lpi && q < 32) dst[q * AST + 64 + tc] = (tok && q < nat) ? pt[i] : 0.f;
+        }
+        if (x_pref) {
+#pragma unroll
+            for (int e = 0; e < CH_XE; ++e) {
+                const int i = threadIdx.x + e * kBlock;
+                size_t o;
+                const bool in = x_addr(i, n_, r0_, t0_, o);
+                if (i < xelems) {
+                    Xv[i] = in ? pxv[e] : 0.f;
+                    Xr[i] = in ? pxr[e] : 0.f;
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < xelems; i += kBlock) {
+                size_t o;
+                const bool in = x_addr(i, n_, r0_, t0_, o);
+                Xv[i] = in ? V[o] : 0.f;
+                Xr[i] = in ? Rr[o] : 0.f;
+            }
+        }
+    };
 
-        // k loop over the CH_TW pixels of this wave's row, two per MFMA, unrolled by two with two operand sets
-        const float *ha = Hs + j * CH_AST + wave * CH_TW + h;
+    const int items = g.N * cg.rblocks * cg.cblocks;
+    if (p < items) prefetch(p);
+    for (int it = p; it < items; it += cg.P) {
+        __syncthreads();   // every wave is done with the previous item's tiles
+        commit(it);
+        __syncthreads();
+        if (it + cg.P < items) prefetch(it + cg.P);   // in flight under the MFMAs below
+
+        // flattened k loop: 2 rows x TW/4 pixel quads; A offsets are linear, B offsets step by XST at the row change
+        const float *ha = Hs + (ah * 16 + j) * AST + (2 * kh) * TW + kq;
+        const int nq = TW >> 2, nsteps = 2 * nq;
+        int st = 0, sq = 0, xo = 0;
         float hA, vA[NT], rA[NT], hB, vB[NT], rB[NT];
-#define CH_LOAD(h_, v_, r_, K2)                                         \
+#define CH_LOAD(h_, v_, r_)                                             \
     do {                                                                \
-        h_ = ha[K2];                                                    \
+        h_ = ha[st * 4];                                                \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) {                \
-            v_[t] = Xv[bo[t] + (K2)];                                   \
-            r_[t] = Xr[bo[t] + (K2)];                                   \
+            v_[t] = Xv[bo[t] + xo];                                     \
+            r_[t] = Xr[bo[t] + xo];                                     \
         }                                                               \
+    } while (0)
+#define CH_NEXT()                   \
+    do {                            \
+        ++st;                       \
+        ++sq;                       \
+        xo += 4;                    \
+        if (sq == nq) {             \
+            sq = 0;                 \
+            xo += XST - TW;         \
+        }                           \
     } while (0)
 #define CH_MMA(h_, v_, r_)                                              \
     do {                                                                \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) {                \
-            accv[t] = mfma32(h_, v_[t], accv[t]);                       \
-            accr[t] = mfma32(h_, r_[t], accr[t]);                       \
+            accv[t] = mfma16(h_, v_[t], accv[t]);                       \
+            accr[t] = mfma16(h_, r_[t], accr[t]);                       \
         }                                                               \
     } while (0)
-        CH_LOAD(hA, vA, rA, 0);
-        for (int k2 = 0; k2 < CH_TW; k2 += 4) {
-            CH_LOAD(hB, vB, rB, k2 + 2);
+        CH_LOAD(hA, vA, rA);
+        while (st + 2 <= nsteps) {
+            CH_NEXT();
+            CH_LOAD(hB, vB, rB);
             __builtin_amdgcn_sched_barrier(0);
             CH_MMA(hA, vA, rA);
-            if (k2 + 4 < CH_TW) CH_LOAD(hA, vA, rA, k2 + 4);
+            CH_NEXT();
+            if (st < nsteps) CH_LOAD(hA, vA, rA);
             __builtin_amdgcn_sched_barrier(0);
             CH_MMA(hB, vB, rB);
         }
+        if (st < nsteps) CH_MMA(hA, vA, rA);
 #undef CH_LOAD
+#undef CH_NEXT
 #undef CH_MMA
     }
 
-    // fold the 4 waves (they split K) through LDS in fixed order, then write this block's partial in double
+    // fold the two row-pair waves of each atom half through LDS (fixed order), write this block's partial in double
     __syncthreads();
-    float *red = smem;   // [4 waves][32 rows? no: per wave NT*2*16 regs x 64 lanes] -> reduce tile by tile
+    float *red = smem;   // [4 waves][2][4 regs][64 lanes], one column tile at a time
     const int MC = g.M * g.C;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        // stage: red[wave][which][r][lane]
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            red[((wave * 2 + 0) * 16 + r) * 64 + lane] = accv[t][r];
-            red[((wave * 2 + 1) * 16 + r) * 64 + lane] = accr[t][r];
+        for (int r = 0; r < 4; ++r) {
+            red[((wave * 2 + 0) * 4 + r) * 64 + lane] = accv[t][r];
+            red[((wave * 2 + 1) * 4 + r) * 64 + lane] = accr[t][r];
         }
         __syncthreads();
-        // thread -> (which, r, lane'): 2*16*64 = 2048 values, 8 per thread
-        for (int e = threadIdx.x; e < 2 * 16 * 64; e += kBlock) {
-            const int ln = e & 63, r = (e >> 6) & 15, which = e >> 10;
-            double s = 0.0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) s += (double)red[((w * 2 + which) * 16 + r) * 64 + ln];
-            const int col = (jg * NT + t) * 32 + (ln & 31);
-            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        for (int e = threadIdx.x; e < 2 * 2 * 4 * 64; e += kBlock) {
+            const int ln = e & 63;
+            const int r = (e >> 6) & 3;
+            const int which = (e >> 8) & 1;
+            const int half = e >> 9;
+            const float s0 = red[(((half * 2 + 0) * 2 + which) * 4 + r) * 64 + ln];
+            const float s1 = red[(((half * 2 + 1) * 2 + which) * 4 + r) * 64 + ln];
+            const int col = (jg * NT + t) * 16 + (ln & 15);
+            const int m = mt * 32 + half * 16 + 4 * (ln >> 4) + r;
             if (col < J && m < g.M) {
                 const int c = col / nA, sft = col - c * nA;
-                partials[(((size_t)p * MC + (size_t)m * g.C + c) * nA + sft) * 2 + which] = s;
+                partials[(((size_t)p * MC + (size_t)m * g.C + c) * nA + sft) * 2 + which] = (double)s0 + (double)s1;
             }
         }
         __syncthreads();
@@ -367,7 +470,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
     const int n = bid / cgroups;
     const int c0 = cg * CB, x0 = xb * 64;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: lives in an SGPR
     const int j = lane & 15, kq = lane >> 4;
     const int gmax = (g.Ay - 1) >> 2;
     const int nA = g.Ay * g.Ax;
@@ -379,44 +483,51 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
     // ---- staging map of this thread (fixed over the sweep).  Lines = (atom ml, row) pairs, line = ml*RC_RBK + row;
     // wave w stages lines w, w+4, ...: columns 0..63 one per lane ("main"), columns 64..HST-1 packed lpi lines per
     // instruction ("tail").  The values of stage s+1 are fetched into registers while stage s is being multiplied.
-    const int nlines = MB * RC_RBK;
-    const int lpw = (nlines + 3) >> 2;
     const int lpi = 64 / Axp4;                       // lines per tail instruction
-    const int ntail = (lpw + lpi - 1) / lpi;
+    const int ntail = (MB + lpi - 1) / lpi;
     const int tl = lane / Axp4, tc = lane - tl * Axp4;
     const bool main_ok = x0 + lane < g.Hx;
     const bool tail_ok = tl < lpi && x0 + 64 + tc < g.Hx;
     const float *Hn = H + (size_t)n * g.M * g.Hy * g.Hx + x0;
     float pm[RC_MAXLPW], pt[RC_MAXTAIL];
 
+    // line wave + 4q is (atom q of the chunk, row wave): one running pointer with the (opaque) atom stride
     auto prefetch = [&](int stage) {
         const int rb0 = (stage / nchunks) * RC_RBK;
         const int m0 = (stage % nchunks) * MB;
+        size_t astr = (size_t)g.Hy * g.Hx;
+        asm volatile("" : "+s"(astr));
+        const int r = rb0 + wave;
+        int nat = g.M - m0;              // atoms of this chunk that exist (>= 1)
+        if (nat > MB) nat = MB;
+        // loads are unconditional on clamped (always valid) addresses and zeroed afterwards: no branch per load
+        const int rc = r < g.Hy ? r : g.Hy - 1;
+        const int lc = main_ok ? lane : g.Hx - 1 - x0;
+        const int tcc = x0 + 64 + tc < g.Hx ? 64 + tc : g.Hx - 1 - x0;
+        const float *src = Hn + ((size_t)m0 * g.Hy + rc) * g.Hx;
+        // NB: the raw values stay untouched until commit() masks them, so nothing waits on these loads here
 #pragma unroll
-        for (int q = 0; q < RC_MAXLPW; ++q) {
-            const int line = wave + 4 * q;
-            const int m = m0 + (line >> 2), r = rb0 + (line & 3);
-            const bool ok = q < lpw && line < nlines && m < g.M && r < g.Hy && main_ok;
-            pm[q] = ok ? Hn[((size_t)m * g.Hy + r) * g.Hx + lane] : 0.f;
-        }
+        for (int q = 0; q < RC_MAXLPW; ++q) pm[q] = src[(q < nat ? q : nat - 1) * astr + lc];
 #pragma unroll
         for (int i = 0; i < RC_MAXTAIL; ++i) {
-            const int line = wave + 4 * (i * lpi + tl);
-            const int m = m0 + (line >> 2), r = rb0 + (line & 3);
-            const bool ok = i < ntail && i * lpi + tl < lpw && line < nlines && m < g.M && r < g.Hy && tail_ok;
-            pt[i] = ok ? Hn[((size_t)m * g.Hy + r) * g.Hx + 64 + tc] : 0.f;
+            const int q = i * lpi + tl;
+            if (i < ntail) pt[i] = src[(q < nat ? q : nat - 1) * astr + tcc];
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int stage) {
+        const int r = (stage / nchunks) * RC_RBK + wave;
+        int nat = g.M - (stage % nchunks) * MB;
+        if (nat > MB) nat = MB;
+        const bool mok = r < g.Hy && main_ok;
+        const bool tok = r < g.Hy && tail_ok;
+        float *dst = Hs + wave * HST;
 #pragma unroll
-        for (int q = 0; q < RC_MAXLPW; ++q) {
-            const int line = wave + 4 * q;
-            if (q < lpw && line < nlines) Hs[line * HST + lane] = pm[q];
-        }
+        for (int q = 0; q < RC_MAXLPW; ++q)
+            if (q < MB) dst[q * RC_RBK * HST + lane] = (mok && q < nat) ? pm[q] : 0.f;
 #pragma unroll
         for (int i = 0; i < RC_MAXTAIL; ++i) {
-            const int line = wave + 4 * (i * lpi + tl);
-            if (i < ntail && tl < lpi && i * lpi + tl < lpw && line < nlines) Hs[line * HST + 64 + tc] = pt[i];
+            const int q = i * lpi + tl;
+            if (i < ntail && tl < lpi && q < MB) dst[q * RC_RBK * HST + 64 + tc] = (tok && q < nat) ? pt[i] : 0.f;
         }
     };
 
@@ -449,7 +560,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
                     Wl[i] = ok ? W[((size_t)m * g.C + c) * nA + (g.Ay - 1 - a) * g.Ax + (g.Ax - 1 - b)] : 0.f;
                 }
             }
-            commit();
+            commit(stage);
             __syncthreads();
             if (stage + 1 < nstages) prefetch(stage + 1);   // in flight under the MFMAs below
 
@@ -558,30 +669,39 @@ ReconPlan plan_reconstruct(const Geo &g) {
 }
 
 struct CorrHPlan {
-    int NT, JG, MT, rblocks, cblocks, P;
+    int NT, JG, MT;
+    CorrHGeom cg;
     size_t lds;
 };
 
 CorrHPlan plan_corr_H(const tnmf_hip_ctx *ctx, const Geo &g) {
     CorrHPlan pl;
     const int J = g.C * g.Ay * g.Ax;
-    const int tiles = cdiv(J, 32);
-    pl.JG = cdiv(tiles, 5);
+    const int tiles = cdiv(J, 16);
+    pl.JG = cdiv(tiles, 12);
     pl.NT = cdiv(tiles, pl.JG);
     pl.MT = cdiv(g.M, 32);
-    pl.rblocks = cdiv(g.Hy, CH_RH);
-    pl.cblocks = cdiv(g.Hx, CH_TW);
-    const long items = (long)g.N * pl.rblocks * pl.cblocks;
+    CorrHGeom &cg = pl.cg;
+    cg.cblocks = cdiv(g.Hx, 72);
+    cg.TW = (cdiv(g.Hx, cg.cblocks) + 3) & ~3;
+    cg.XSTW = (cg.TW + 31) & ~31;
+    cg.AST = CH_RH * cg.TW;
+    while ((cg.AST & 31) != 2) ++cg.AST;
+    cg.rblocks = cdiv(g.Hy, CH_RH);
+    const long items = (long)g.N * cg.rblocks * cg.cblocks;
     long P = (2L * ctx->num_cu) / ((long)pl.MT * pl.JG);
     if (P < 1) P = 1;
-    // keep one f32 accumulation chain below ~32K terms (K per block = items/P * CH_TW per wave)
-    const long minP = (items * CH_TW + 32767) / 32768;
+    // keep one f32 accumulation chain below ~32K terms (K per block and wave = items/P * 2 * TW)
+    const long minP = (items * 2 * cg.TW + 32767) / 32768;
     if (P < minP) P = minP;
     if (P > items) P = items;
     if (P > 8192) P = 8192;
-    pl.P = (int)P;
-    const size_t stage = ((size_t)32 * CH_AST + 2 * ((size_t)g.C * (CH_RH + g.Ay - 1) * (CH_TW + g.Ax) + CH_ZL)) * sizeof(float);
-    const size_t red = (size_t)4 * 2 * 16 * 64 * sizeof(float);
+    cg.P = (int)P;
+    const int XST = cg.XSTW + g.Ax;
+    const size_t plane = (size_t)(CH_RH + g.Ay - 1) * XST;
+    const size_t ZL = cg.TW + XST + 8;
+    const size_t stage = ((size_t)32 * cg.AST + 2 * ((size_t)g.C * plane + ZL)) * sizeof(float);
+    const size_t red = (size_t)4 * 2 * 4 * 64 * sizeof(float);
     pl.lds = stage > red ? stage : red;
     return pl;
 }
@@ -614,7 +734,7 @@ bool mfma_has_corr_H(const Geo &g, int dtype) {
     tnmf_hip_ctx fake{};
     fake.num_cu = 256;
     const CorrHPlan pl = plan_corr_H(&fake, g);
-    return pl.lds <= 64 * 1024 && pl.NT <= 5;
+    return pl.lds <= 64 * 1024 && pl.NT <= 12 && pl.cg.TW <= 72 && (pl.cg.TW <= 64 || (32 + 64 / (pl.cg.TW - 64) - 1) / (64 / (pl.cg.TW - 64)) <= CH_MAXTAIL);
 }
 
 int mfma_reconstruct(tnmf_hip_ctx *, const Geo &g, const float *W, const float *H, float *R, hipStream_t s) {
@@ -661,23 +781,29 @@ int mfma_corr_W(tnmf_hip_ctx *, const Geo &g, const float *V, const float *R, co
 
 int mfma_corr_H_chunks(const tnmf_hip_ctx *ctx, const Geo &g) {
     if (!mfma_has_corr_H(g, 0)) return 0;
-    return plan_corr_H(ctx, g).P;
+    return plan_corr_H(ctx, g).cg.P;
 }
 
 int mfma_corr_H(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *H, double *partials,
                 int P, hipStream_t s) {
     const CorrHPlan pl = plan_corr_H(ctx, g);
-    if (P != pl.P) return TNMF_E_WORKSPACE;
-    const dim3 grid(pl.P, pl.MT, pl.JG);
-#define LAUNCH_CH(NT_)                                                                                             \
-    hipLaunchKernelGGL((k_mfma_corr_H<NT_>), grid, dim3(kBlock), pl.lds, s, g, pl.P, pl.rblocks, pl.cblocks, V, R, H, \
-                       partials)
+    if (P != pl.cg.P) return TNMF_E_WORKSPACE;
+    const dim3 grid(pl.cg.P, pl.MT, pl.JG);
+#define LAUNCH_CH(NT_) \
+    case NT_: hipLaunchKernelGGL((k_mfma_corr_H<NT_>), grid, dim3(kBlock), pl.lds, s, g, pl.cg, V, R, H, partials); break
     switch (pl.NT) {
-        case 1: LAUNCH_CH(1); break;
-        case 2: LAUNCH_CH(2); break;
-        case 3: LAUNCH_CH(3); break;
-        case 4: LAUNCH_CH(4); break;
-        case 5: LAUNCH_CH(5); break;
+        LAUNCH_CH(1);
+        LAUNCH_CH(2);
+        LAUNCH_CH(3);
+        LAUNCH_CH(4);
+        LAUNCH_CH(5);
+        LAUNCH_CH(6);
+        LAUNCH_CH(7);
+        LAUNCH_CH(8);
+        LAUNCH_CH(9);
+        LAUNCH_CH(10);
+        LAUNCH_CH(11);
+        LAUNCH_CH(12);
         default: return TNMF_E_UNSUPPORTED;
     }
 #undef LAUNCH_CH
