@@ -50,9 +50,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
     const int Axp = (g.Ax + 1) & ~1;
     const int SH = CW_TY + g.Ay - 1;
     const int KC = g.Ay * Axp;
-    float *Vs = smem;
-    float *Rs = Vs + SH * CW_XSTR;
-    float *Ws = Rs + SH * CW_XSTR;   // [KC][32]
+    float2 *Xs = reinterpret_cast<float2 *>(smem);   // [SH][CW_XSTR] of (V, R): one ds_read_b64 feeds both MFMAs
+    float *Ws = smem + 2 * SH * CW_XSTR;             // [KC][32]
 
     unsigned bid = blockIdx.x;
     const int txi = bid % tiles_x;
@@ -85,8 +84,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
             const int y = u0 + rr - (g.Ay - 1), x = v0 + q - (g.Ax - 1);
             const bool in = (q < need_w) && y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
             const size_t o = (size_t)y * g.Dx + x;
-            Vs[i] = in ? v[o] : 0.f;
-            Rs[i] = in ? r[o] : 0.f;
+            Xs[i] = in ? float2{v[o], r[o]} : float2{0.f, 0.f};
         }
         for (int i = threadIdx.x; i < KC * 32; i += kBlock) {
             const int kk = i >> 5, mi = i & 31;
@@ -97,20 +95,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
         __syncthreads();
 
         // flattened k loop over (a, b-pair), unrolled by two with two operand register sets: the LDS reads of step
-        // st+1 are issued before the MFMAs of step st, so the matrix pipe never waits on LDS latency
-        const float *vb = Vs + (wave * CW_RB) * CW_XSTR + j + h;
-        const float *rb_ = Rs + (wave * CW_RB) * CW_XSTR + j + h;
+        // st+1 (one W word + CW_RB (V,R) pairs = 5 reads) are issued before the MFMAs of step st
+        const float2 *xb = Xs + (wave * CW_RB) * CW_XSTR + j + h;
         const float *wb = Ws + h * 32 + j;
         const int nsteps = g.Ay * (Axp >> 1);
         int b2 = 0, xo = 0, st = 0;
-        float wA, vA[CW_RB], rA[CW_RB], wB, vB[CW_RB], rB[CW_RB];
-#define CW_LOAD(w_, v_, r_)                                   \
-    do {                                                      \
-        w_ = wb[st * 64];                                     \
-        _Pragma("unroll") for (int rb = 0; rb < CW_RB; ++rb) { \
-            v_[rb] = vb[rb * CW_XSTR + xo];                   \
-            r_[rb] = rb_[rb * CW_XSTR + xo];                  \
-        }                                                     \
+        float wA, wB;
+        float2 xA[CW_RB], xB[CW_RB];
+#define CW_LOAD(w_, x_)                                                                      \
+    do {                                                                                     \
+        w_ = wb[st * 64];                                                                    \
+        _Pragma("unroll") for (int rb = 0; rb < CW_RB; ++rb) x_[rb] = xb[rb * CW_XSTR + xo]; \
     } while (0)
 #define CW_NEXT()                  \
     do {                           \
@@ -122,25 +117,25 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
             xo += CW_XSTR - Axp;   \
         }                          \
     } while (0)
-#define CW_MMA(w_, v_, r_)                                    \
+#define CW_MMA(w_, x_)                                        \
     do {                                                      \
         _Pragma("unroll") for (int rb = 0; rb < CW_RB; ++rb) { \
-            an[rb] = mfma32(w_, v_[rb], an[rb]);              \
-            ap[rb] = mfma32(w_, r_[rb], ap[rb]);              \
+            an[rb] = mfma32(w_, x_[rb].x, an[rb]);            \
+            ap[rb] = mfma32(w_, x_[rb].y, ap[rb]);            \
         }                                                     \
     } while (0)
-        CW_LOAD(wA, vA, rA);
+        CW_LOAD(wA, xA);
         while (st + 2 <= nsteps) {
             CW_NEXT();
-            CW_LOAD(wB, vB, rB);
+            CW_LOAD(wB, xB);
             __builtin_amdgcn_sched_barrier(0);
-            CW_MMA(wA, vA, rA);
+            CW_MMA(wA, xA);
             CW_NEXT();
-            if (st < nsteps) CW_LOAD(wA, vA, rA);
+            if (st < nsteps) CW_LOAD(wA, xA);
             __builtin_amdgcn_sched_barrier(0);
-            CW_MMA(wB, vB, rB);
+            CW_MMA(wB, xB);
         }
-        if (st < nsteps) CW_MMA(wA, vA, rA);
+        if (st < nsteps) CW_MMA(wA, xA);
 #undef CW_LOAD
 #undef CW_NEXT
 #undef CW_MMA
@@ -190,7 +185,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
 //   X[c][r - a'][t - b'] with J = c*nA + a'*Ax + b' (zero outside the sample; columns beyond J walk a zero strip).
 //   The 4 waves are (atom half ah, row pair kh): wave (ah, kh) multiplies atoms 16*ah..16*ah+15 with rows 2*kh, 2*kh+1
 //   of the tile for all NT 16-column tiles of its column group, for V and for R: 2*NT accumulators of 16x16.
-//   Layout notes: H tile atom stride == 2 (mod 32) and X row stride == Ax (mod 32) make both operand reads
+//   Layout notes: H tile atom stride == 2 (mod 32) and X row stride == Ax + 1 (mod 32) make both operand reads
 //   conflict-free (a wave reads 64 consecutive-ish words).  The next item's H tile and X windows are fetched into
 //   registers while the current item is multiplied.
 //   Output: partials[p][m*C + c][s = a'*Ax + b'][{V, R}] in double (summed in fixed order by k_corr_H_finalize).
@@ -209,14 +204,12 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, con
                                                            const float *__restrict__ H, double *__restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TW = cg.TW, AST = cg.AST;
-    const int XST = cg.XSTW + g.Ax;
+    const int XST = cg.XSTW + g.Ax + 1;   // == Ax + 1 (mod 32): conflict-free B reads (see tools/lds_conflicts.py)
     const int XR = CH_RH + g.Ay - 1;
     const int plane = XR * XST;              // one channel of one of V / R
     const int ZL = TW + XST + 8;             // zero strip behind the windows
-    const int RS = g.C * plane + ZL;         // distance from the V windows to the R windows
-    float *Hs = smem;                        // [32][AST]
-    float *Xv = Hs + 32 * AST;               // [C][XR][XST] then ZL zeros
-    float *Xr = Xv + RS;
+    float *Hs = smem;                        // [32][AST]  (AST even: the float2 region below stays 8-byte aligned)
+    float2 *Xs = reinterpret_cast<float2 *>(Hs + 32 * AST);   // [C][XR][XST] of (V, R), then ZL zero pairs
 
     const int p = blockIdx.x, mt = blockIdx.y, jg = blockIdx.z;
     const int lane = threadIdx.x & 63;
@@ -245,10 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, con
         accv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         accr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int i = threadIdx.x; i < ZL; i += kBlock) {
-        Xv[g.C * plane + i] = 0.f;
-        Xr[g.C * plane + i] = 0.f;
-    }
+    for (int i = threadIdx.x; i < ZL; i += kBlock) Xs[g.C * plane + i] = float2{0.f, 0.f};
 
     // ---- staging map (fixed): H tile lines = (atom mi, row), line = mi*CH_RH + row, 128 lines; wave w stages lines
     // w, w+4, ...: columns 0..63 one per lane, columns 64..TW-1 packed lpi lines per instruction
@@ -334,17 +324,13 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, con
                 const int i = threadIdx.x + e * kBlock;
                 size_t o;
                 const bool in = x_addr(i, n_, r0_, t0_, o);
-                if (i < xelems) {
-                    Xv[i] = in ? pxv[e] : 0.f;
-                    Xr[i] = in ? pxr[e] : 0.f;
-                }
+                if (i < xelems) Xs[i] = in ? float2{pxv[e], pxr[e]} : float2{0.f, 0.f};
             }
         } else {
             for (int i = threadIdx.x; i < xelems; i += kBlock) {
                 size_t o;
                 const bool in = x_addr(i, n_, r0_, t0_, o);
-                Xv[i] = in ? V[o] : 0.f;
-                Xr[i] = in ? Rr[o] : 0.f;
+                Xs[i] = in ? float2{V[o], Rr[o]} : float2{0.f, 0.f};
             }
         }
     };
@@ -357,51 +343,39 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, con
         __syncthreads();
         if (it + cg.P < items) prefetch(it + cg.P);   // in flight under the MFMAs below
 
-        // flattened k loop: 2 rows x TW/4 pixel quads; A offsets are linear, B offsets step by XST at the row change
+        // flattened k loop: 2 rows x TW/4 pixel quads; A offsets are linear, B offsets step by XST at the row change.
+        // Fine-grained software pipeline: right after the two MFMAs of column tile t its (V,R) operand pair is reloaded
+        // for the NEXT k step (one ds_read_b64), so each LDS read has a whole step of MFMAs to land and at most NT+1
+        // reads are outstanding (the lgkm counter saturates at 15).
         const float *ha = Hs + (ah * 16 + j) * AST + (2 * kh) * TW + kq;
         const int nq = TW >> 2, nsteps = 2 * nq;
-        int st = 0, sq = 0, xo = 0;
-        float hA, vA[NT], rA[NT], hB, vB[NT], rB[NT];
-#define CH_LOAD(h_, v_, r_)                                             \
-    do {                                                                \
-        h_ = ha[st * 4];                                                \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                \
-            v_[t] = Xv[bo[t] + xo];                                     \
-            r_[t] = Xr[bo[t] + xo];                                     \
-        }                                                               \
-    } while (0)
-#define CH_NEXT()                   \
-    do {                            \
-        ++st;                       \
-        ++sq;                       \
-        xo += 4;                    \
-        if (sq == nq) {             \
-            sq = 0;                 \
-            xo += XST - TW;         \
-        }                           \
-    } while (0)
-#define CH_MMA(h_, v_, r_)                                              \
-    do {                                                                \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                \
-            accv[t] = mfma16(h_, v_[t], accv[t]);                       \
-            accr[t] = mfma16(h_, r_[t], accr[t]);                       \
-        }                                                               \
-    } while (0)
-        CH_LOAD(hA, vA, rA);
-        while (st + 2 <= nsteps) {
-            CH_NEXT();
-            CH_LOAD(hB, vB, rB);
-            __builtin_amdgcn_sched_barrier(0);
-            CH_MMA(hA, vA, rA);
-            CH_NEXT();
-            if (st < nsteps) CH_LOAD(hA, vA, rA);
-            __builtin_amdgcn_sched_barrier(0);
-            CH_MMA(hB, vB, rB);
+        int sq = 0, xo = 0;
+        float hv = ha[0];
+        float2 bx[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bx[t] = Xs[bo[t]];
+        for (int st = 1; st < nsteps; ++st) {
+            ++sq;
+            xo += 4;
+            if (sq == nq) {
+                sq = 0;
+                xo += XST - TW;
+            }
+            const float hn = ha[st * 4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                accv[t] = mfma16(hv, bx[t].x, accv[t]);
+                accr[t] = mfma16(hv, bx[t].y, accr[t]);
+                bx[t] = Xs[bo[t] + xo];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            hv = hn;
         }
-        if (st < nsteps) CH_MMA(hA, vA, rA);
-#undef CH_LOAD
-#undef CH_NEXT
-#undef CH_MMA
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            accv[t] = mfma16(hv, bx[t].x, accv[t]);
+            accr[t] = mfma16(hv, bx[t].y, accr[t]);
+        }
     }
 
     // fold the two row-pair waves of each atom half through LDS (fixed order), write this block's partial in double
@@ -697,10 +671,10 @@ CorrHPlan plan_corr_H(const tnmf_hip_ctx *ctx, const Geo &g) {
     if (P > items) P = items;
     if (P > 8192) P = 8192;
     cg.P = (int)P;
-    const int XST = cg.XSTW + g.Ax;
+    const int XST = cg.XSTW + g.Ax + 1;
     const size_t plane = (size_t)(CH_RH + g.Ay - 1) * XST;
     const size_t ZL = cg.TW + XST + 8;
-    const size_t stage = ((size_t)32 * cg.AST + 2 * ((size_t)g.C * plane + ZL)) * sizeof(float);
+    const size_t stage = ((size_t)32 * cg.AST + 2 * ((size_t)g.C * plane + ZL)) * sizeof(float);   // (V,R) pairs
     const size_t red = (size_t)4 * 2 * 4 * 64 * sizeof(float);
     pl.lds = stage > red ? stage : red;
     return pl;
