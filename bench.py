@@ -79,6 +79,17 @@ def synth_V_on_device(cfg, n_local, seed, device):
     return out
 
 
+def measured_traffic(kernel_name, cfg_id, path):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), config 3 / MFMA path only."""
+    f = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    if cfg_id != 3 or path != 'mfma' or not os.path.exists(f):
+        return None
+    try:
+        return json.load(open(f))['kernels'][kernel_name]['traffic_bytes']
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, budget_s=20.0):
     """Time the oracle's contraction form (the reference NumPy backend's algorithm) on a few samples of the workload."""
     from oracle import tnmf_oracle as orc
@@ -217,7 +228,8 @@ def main():
             'kernels': kernels,
             'roofline': {
                 'kernel': dom, 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_F32_TFLOPS, 'traffic': None,
+                'frac': achieved / PEAK_F32_TFLOPS,
+                'traffic': measured_traffic(dom, args.config, be.last_path) if not args.samples else None,
                 'flops_per_launch': flops_per_launch[dom], 'avg_launch_ms': kernels[dom]['avg_ms'],
             },
         }

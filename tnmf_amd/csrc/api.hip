@@ -1,6 +1,7 @@
 // api.hip -- the extern "C" surface of libtnmf_hip.so (include/tnmf_hip.h): argument checks, scratch management and
 // dispatch between the kernel families.  No torch types, no exceptions, no allocation inside a call once
 // tnmf_hip_ctx_reserve() has sized the scratch.
+#include <cstdlib>
 #include <new>
 
 #include "generic.h"
@@ -186,6 +187,10 @@ int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out) {
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->path = TNMF_PATH_AUTO;
     ctx->last_path = "none";
+    {
+        const char *ab = getenv("TNMF_HIP_ABLATE");   // diagnostic builds of the timing harness only
+        ctx->ablate = ab ? atoi(ab) : 0;
+    }
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     *out = ctx;

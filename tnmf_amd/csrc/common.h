@@ -20,6 +20,7 @@ struct tnmf_hip_ctx {
     int num_cu;
     int path;               // TNMF_PATH_*
     const char *last_path;  // "generic" | "mfma"
+    int ablate;             // diagnostic only (env TNMF_HIP_ABLATE at ctx creation): kernels skip phases; results wrong
     void *ws;               // scratch: [R | split-K partials | reduction words]
     size_t ws_bytes;
 };

@@ -42,7 +42,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 constexpr int CW_TY = 16, CW_TX = 32, CW_RB = 4, CW_XSTR = 64;
 
 template <bool FUSED>
-__global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, int tiles_x, int MT,
+__global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, int tiles_x, int MT, int ablate,
                                                         const float *__restrict__ V, const float *__restrict__ Rr,
                                                         const float *__restrict__ W, float *__restrict__ Hio,
                                                         float *__restrict__ neg, float *__restrict__ pos, float reg) {
@@ -75,10 +75,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
         ap[rb] = zero16();
     }
 
+    const int vv = v0 + j;
+    const size_t mstride = (size_t)g.Hy * g.Hx;
+
     for (int c = 0; c < g.C; ++c) {
         const float *v = V + ((size_t)n * g.C + c) * g.Dy * g.Dx;
         const float *r = Rr + ((size_t)n * g.C + c) * g.Dy * g.Dx;
         __syncthreads();
+        if (!(ablate & 1))
         for (int i = threadIdx.x; i < SH * CW_XSTR; i += kBlock) {
             const int rr = i / CW_XSTR, q = i - rr * CW_XSTR;
             const int y = u0 + rr - (g.Ay - 1), x = v0 + q - (g.Ax - 1);
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
             const size_t o = (size_t)y * g.Dx + x;
             Xs[i] = in ? float2{v[o], r[o]} : float2{0.f, 0.f};
         }
+        if (!(ablate & 2))
         for (int i = threadIdx.x; i < KC * 32; i += kBlock) {
             const int kk = i >> 5, mi = i & 31;
             const int a = kk / Axp, b = kk - a * Axp;
@@ -124,6 +129,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
             ap[rb] = mfma32(w_, x_[rb].y, ap[rb]);            \
         }                                                     \
     } while (0)
+        if (ablate & 4) st = nsteps;
         CW_LOAD(wA, xA);
         while (st + 2 <= nsteps) {
             CW_NEXT();
@@ -142,11 +148,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
     }
 
     // epilogue.  Lane (j, h) holds pixel column v0+j of 16 atoms per accumulator: for a fixed register the 32 lanes of a
-    // half write 128 contiguous bytes.  The H values of one tile row are all loaded before the first store so that the
-    // 16 loads are independent (one memory round trip per row, not one per element).
-    const int vv = v0 + j;
-    if (vv < g.Hx) {
-        const size_t mstride = (size_t)g.Hy * g.Hx;
+    // half touch 128 contiguous bytes.  FUSED: the 16 H values of one tile row are loaded before the first store so that
+    // the loads are independent: one memory round trip per tile row.  (Loading all four rows at once costs a wave of
+    // occupancy and measured slower; see DESIGN.md.)
+    if (vv < g.Hx && !(ablate & 8)) {
 #pragma unroll
         for (int rb = 0; rb < CW_RB; ++rb) {
             const int u = u0 + wave * CW_RB + rb;
@@ -737,7 +742,7 @@ int mfma_reconstruct(tnmf_hip_ctx *, const Geo &g, const float *W, const float *
     return TNMF_OK;
 }
 
-int mfma_corr_W(tnmf_hip_ctx *, const Geo &g, const float *V, const float *R, const float *W, float *H_inout,
+int mfma_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *W, float *H_inout,
                 float *neg, float *pos, bool fused, float reg, hipStream_t s) {
     const int tiles_y = cdiv(g.Hy, CW_TY), tiles_x = cdiv(g.Hx, CW_TX), MT = cdiv(g.M, 32);
     const size_t lds = ((size_t)2 * (CW_TY + g.Ay - 1) * CW_XSTR + (size_t)g.Ay * ((g.Ax + 1) & ~1) * 32) * sizeof(float);
@@ -745,10 +750,10 @@ int mfma_corr_W(tnmf_hip_ctx *, const Geo &g, const float *V, const float *R, co
     if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
     if (fused)
         hipLaunchKernelGGL((k_mfma_corr_W<true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, g, tiles_y, tiles_x, MT,
-                           V, R, W, H_inout, (float *)nullptr, (float *)nullptr, reg);
+                           ctx->ablate, V, R, W, H_inout, (float *)nullptr, (float *)nullptr, reg);
     else
         hipLaunchKernelGGL((k_mfma_corr_W<false>), dim3((unsigned)blocks), dim3(kBlock), lds, s, g, tiles_y, tiles_x,
-                           MT, V, R, W, (float *)nullptr, neg, pos, 0.f);
+                           MT, ctx->ablate, V, R, W, (float *)nullptr, neg, pos, 0.f);
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
 }
