@@ -204,7 +204,7 @@ struct CorrHGeom {
 };
 
 template <int NT>
-__global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, const float *__restrict__ V,
+__global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, int ablate, const float *__restrict__ V,
                                                            const float *__restrict__ Rr,
                                                            const float *__restrict__ H, double *__restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, con
     };
     // X-window element i of an item: returns whether it lies inside the sample; the address is clamped so that the
     // load itself is always legal (the value is masked when it is written to LDS)
-    auto x_addr = [&](int i, int n, int r0, int t0, size_t &o) -> bool {
+    auto x_addr = [&](int i, int r0, int t0, unsigned &o) -> bool {   // o: element offset inside sample n
         const int ic = i < xelems ? i : 0;
         const int c = ic / plane;
         const int rem = ic - c * plane;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, con
         const int y = r0 - (g.Ay - 1) + row, x = t0 - (g.Ax - 1) + col;
         const bool in = i < xelems && y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
         const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1), xc = x < 0 ? 0 : (x < g.Dx ? x : g.Dx - 1);
-        o = (((size_t)n * g.C + c) * g.Dy + yc) * g.Dx + xc;
+        o = (unsigned)((c * g.Dy + yc) * g.Dx + xc);
         return in;
     };
     // line wave + 4q of the tile is (atom q, row wave): one running pointer with the atom stride, which is made
@@ -285,26 +285,32 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, con
         asm volatile("" : "+s"(astr));
         const int r = r0 + wave;
         const int nat = g.M - mt * 32;   // atoms of this tile that exist (>= 1)
-        // loads are unconditional on clamped (always valid) addresses and zeroed afterwards: no branch per load
+        // loads are unconditional on clamped (always valid) addresses and masked at commit: no branch per load, and
+        // every address is a wave-uniform base (SGPRs) plus one shared 32-bit lane offset (saddr + voffset form)
         const int rc = r < g.Hy ? r : g.Hy - 1;
-        const int lc = t0 + lane < g.Hx ? lane : g.Hx - 1 - t0;
-        const int tcc = t0 + 64 + tc < g.Hx ? 64 + tc : g.Hx - 1 - t0;
+        const unsigned lc = (unsigned)(t0 + lane < g.Hx ? lane : g.Hx - 1 - t0);
         const float *src = H + (((size_t)n * g.M + mt * 32) * g.Hy + rc) * g.Hx + t0;
-        // NB: the raw values stay untouched until commit() masks them, so nothing waits on these loads here
 #pragma unroll
-        for (int q = 0; q < 32; ++q) pm[q] = src[(q < nat ? q : nat - 1) * astr + lc];
+        for (int q = 0; q < 32; ++q) {
+            const float *sq_ = src + (size_t)(q < nat ? q : nat - 1) * astr;
+            pm[q] = sq_[lc];
+        }
+        const unsigned tcc = (unsigned)(t0 + 64 + tc < g.Hx ? 64 + tc : g.Hx - 1 - t0);
+        const unsigned astr32 = (unsigned)astr;
 #pragma unroll
         for (int i = 0; i < CH_MAXTAIL; ++i) {
             const int q = i * lpi + tl;
-            if (i < ntail) pt[i] = src[(q < nat ? q : nat - 1) * astr + tcc];
+            if (i < ntail) pt[i] = src[(unsigned)(q < nat ? q : nat - 1) * astr32 + tcc];
         }
         if (x_pref) {
+            const float *Vn = V + (size_t)n * g.C * g.Dy * g.Dx;
+            const float *Rn = Rr + (size_t)n * g.C * g.Dy * g.Dx;
 #pragma unroll
             for (int e = 0; e < CH_XE; ++e) {
-                size_t o;
-                (void)x_addr(threadIdx.x + e * kBlock, n, r0, t0, o);
-                pxv[e] = V[o];
-                pxr[e] = Rr[o];
+                unsigned o;
+                (void)x_addr(threadIdx.x + e * kBlock, r0, t0, o);
+                pxv[e] = Vn[o];
+                pxr[e] = Rn[o];
             }
         }
     };
@@ -327,26 +333,28 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, con
 #pragma unroll
             for (int e = 0; e < CH_XE; ++e) {
                 const int i = threadIdx.x + e * kBlock;
-                size_t o;
-                const bool in = x_addr(i, n_, r0_, t0_, o);
+                unsigned o;
+                const bool in = x_addr(i, r0_, t0_, o);
                 if (i < xelems) Xs[i] = in ? float2{pxv[e], pxr[e]} : float2{0.f, 0.f};
             }
         } else {
+            const float *Vn = V + (size_t)n_ * g.C * g.Dy * g.Dx;
+            const float *Rn = Rr + (size_t)n_ * g.C * g.Dy * g.Dx;
             for (int i = threadIdx.x; i < xelems; i += kBlock) {
-                size_t o;
-                const bool in = x_addr(i, n_, r0_, t0_, o);
-                Xs[i] = in ? float2{V[o], Rr[o]} : float2{0.f, 0.f};
+                unsigned o;
+                const bool in = x_addr(i, r0_, t0_, o);
+                Xs[i] = in ? float2{Vn[o], Rn[o]} : float2{0.f, 0.f};
             }
         }
     };
 
     const int items = g.N * cg.rblocks * cg.cblocks;
-    if (p < items) prefetch(p);
+    if (p < items && !(ablate & 1)) prefetch(p);
     for (int it = p; it < items; it += cg.P) {
         __syncthreads();   // every wave is done with the previous item's tiles
-        commit(it);
+        if (!(ablate & 1)) commit(it);
         __syncthreads();
-        if (it + cg.P < items) prefetch(it + cg.P);   // in flight under the MFMAs below
+        if (it + cg.P < items && !(ablate & 1)) prefetch(it + cg.P);   // in flight under the MFMAs below
 
         // flattened k loop: 2 rows x TW/4 pixel quads; A offsets are linear, B offsets step by XST at the row change.
         // Fine-grained software pipeline: right after the two MFMAs of column tile t its (V,R) operand pair is reloaded
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_mfma_corr_H(Geo g, CorrHGeom cg, con
         float2 bx[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) bx[t] = Xs[bo[t]];
-        for (int st = 1; st < nsteps; ++st) {
+        for (int st = (ablate & 4) ? nsteps : 1; st < nsteps; ++st) {
             ++sq;
             xo += 4;
             if (sq == nq) {
@@ -430,8 +438,8 @@ constexpr int RC_RBK = 4;
 constexpr int RC_MAXLPW = 32;    // (atom, row) lines staged per wave: MB * RC_RBK / 4 <= 32
 constexpr int RC_MAXTAIL = 16;   // packed tail loads per wave (tail = columns 64 .. 64+Axp4-1 of a line)
 
-template <int CB>
-__global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, int xblocks, int cgroups,
+template <int CB, int NB>
+__global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, int xblocks, int cgroups, int ablate,
                                                                 const float *__restrict__ W,
                                                                 const float *__restrict__ H, float *__restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -481,16 +489,21 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
         if (nat > MB) nat = MB;
         // loads are unconditional on clamped (always valid) addresses and zeroed afterwards: no branch per load
         const int rc = r < g.Hy ? r : g.Hy - 1;
-        const int lc = main_ok ? lane : g.Hx - 1 - x0;
-        const int tcc = x0 + 64 + tc < g.Hx ? 64 + tc : g.Hx - 1 - x0;
+        const unsigned lc = (unsigned)(main_ok ? lane : g.Hx - 1 - x0);
+        const unsigned tcc = (unsigned)(x0 + 64 + tc < g.Hx ? 64 + tc : g.Hx - 1 - x0);
         const float *src = Hn + ((size_t)m0 * g.Hy + rc) * g.Hx;
-        // NB: the raw values stay untouched until commit() masks them, so nothing waits on these loads here
+        // NB: the raw values stay untouched until commit() masks them, so nothing waits on these loads here; every
+        // address is a wave-uniform base (SGPRs) plus one shared 32-bit lane offset
 #pragma unroll
-        for (int q = 0; q < RC_MAXLPW; ++q) pm[q] = src[(q < nat ? q : nat - 1) * astr + lc];
+        for (int q = 0; q < RC_MAXLPW; ++q) {
+            const float *sq_ = src + (size_t)(q < nat ? q : nat - 1) * astr;
+            pm[q] = sq_[lc];
+        }
+        const unsigned astr32 = (unsigned)astr;
 #pragma unroll
         for (int i = 0; i < RC_MAXTAIL; ++i) {
             const int q = i * lpi + tl;
-            if (i < ntail) pt[i] = src[(q < nat ? q : nat - 1) * astr + tcc];
+            if (i < ntail) pt[i] = src[(unsigned)(q < nat ? q : nat - 1) * astr32 + tcc];
         }
     };
     auto commit = [&](int stage) {
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
 #pragma unroll
     for (int c = 0; c < CB; ++c) w0[c] = w1[c] = w2[c] = 0.f;
 
-    prefetch(0);
+    if (!(ablate & 1)) prefetch(0);
     int stage = 0;
     for (int rb0 = 0; rb0 < rows_total; rb0 += RC_RBK) {
         f32x4 acc[RC_RBK][CB];
@@ -539,17 +552,52 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
                     Wl[i] = ok ? W[((size_t)m * g.C + c) * nA + (g.Ay - 1 - a) * g.Ax + (g.Ax - 1 - b)] : 0.f;
                 }
             }
-            commit(stage);
+            if (!(ablate & 1)) commit(stage);
             __syncthreads();
-            if (stage + 1 < nstages) prefetch(stage + 1);   // in flight under the MFMAs below
+            if (stage + 1 < nstages && !(ablate & 1)) prefetch(stage + 1);   // in flight under the MFMAs below
 
-            // flattened k loop over (atom, b-quad): A offsets are linear in the step, B offsets wrap per atom;
-            // unrolled by two with two operand register sets (LDS reads of step st+1 fly under the MFMAs of step st)
             const float *wl = Wl + kq * 16 + j;
             const float *hb = Hs + wave * 16 + j + kq;
+            if (NB > 0) {
+                // k loop atom by atom, the NB b-quads of an atom fully unrolled (compile-time LDS offsets); operands of
+                // atom ml+1 (NB*CB + NB*RC_RBK reads) are fetched while the NB*RC_RBK*CB MFMAs of atom ml run
+                float aA[NB > 0 ? NB : 1][CB], bA[NB > 0 ? NB : 1][RC_RBK], aB[NB > 0 ? NB : 1][CB], bB[NB > 0 ? NB : 1][RC_RBK];
+#define RCA_LOAD(a_, b_, ML)                                                                               \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                   \
+            _Pragma("unroll") for (int c = 0; c < CB; ++c) a_[q][c] = wl[(c * K4 + ((ML) * NB + q) * 4) * 16]; \
+            _Pragma("unroll") for (int rr = 0; rr < RC_RBK; ++rr) b_[q][rr] = hb[((ML) * RC_RBK + rr) * HST + 4 * q]; \
+        }                                                                                                  \
+    } while (0)
+#define RCA_MMA(a_, b_)                                                                                    \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q)                                                     \
+            _Pragma("unroll") for (int rr = 0; rr < RC_RBK; ++rr)                                          \
+                _Pragma("unroll") for (int c = 0; c < CB; ++c)                                             \
+                    acc[rr][c] = mfma16(a_[q][c], b_[q][rr], acc[rr][c]);                                  \
+    } while (0)
+                if (!(ablate & 4)) {
+                    int ml = 0;
+                    RCA_LOAD(aA, bA, 0);
+                    while (ml + 2 <= MB) {
+                        RCA_LOAD(aB, bB, ml + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        RCA_MMA(aA, bA);
+                        ml += 2;
+                        if (ml < MB) RCA_LOAD(aA, bA, ml);
+                        __builtin_amdgcn_sched_barrier(0);
+                        RCA_MMA(aB, bB);
+                    }
+                    if (ml < MB) RCA_MMA(aA, bA);
+                }
+#undef RCA_LOAD
+#undef RCA_MMA
+            } else {
+            // flattened k loop over (atom, b-quad): A offsets are linear in the step, B offsets wrap per atom;
+            // unrolled by two with two operand register sets (LDS reads of step st+1 fly under the MFMAs of step st)
             const int nb = Axp4 >> 2;
             const int nsteps = MB * nb;
-            int bq = 0, ho = 0, st = 0;
+            int bq = 0, ho = 0, st = (ablate & 4) ? nsteps : 0;
             float aA[CB], bA[RC_RBK], aB[CB], bB[RC_RBK];
 #define RC_LOAD(a_, b_)                                                                     \
     do {                                                                                    \
@@ -587,11 +635,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
 #undef RC_LOAD
 #undef RC_NEXT
 #undef RC_MMA
+            }
         }
 
         // col2im along the row axis, rows of this block in order.  The ring is private to the wave and LDS operations
         // of one wave execute in program order, so the accumulate (ds_add_f32, no return) needs no wait before the
         // read of the finished row; only the compiler has to be kept from reordering them.
+        if (!(ablate & 2))
 #pragma unroll
         for (int rr = 0; rr < RC_RBK; ++rr) {
             const int r = rb0 + rr;
@@ -716,27 +766,36 @@ bool mfma_has_corr_H(const Geo &g, int dtype) {
     return pl.lds <= 64 * 1024 && pl.NT <= 12 && pl.cg.TW <= 72 && (pl.cg.TW <= 64 || (32 + 64 / (pl.cg.TW - 64) - 1) / (64 / (pl.cg.TW - 64)) <= CH_MAXTAIL);
 }
 
-int mfma_reconstruct(tnmf_hip_ctx *, const Geo &g, const float *W, const float *H, float *R, hipStream_t s) {
+int mfma_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, const float *W, const float *H, float *R, hipStream_t s) {
     const ReconPlan pl = plan_reconstruct(g);
     const size_t blocks = (size_t)g.N * pl.cgroups * pl.xblocks;
     if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
-#define LAUNCH_RC(CB_)                                                                                             \
+#define LAUNCH_RC(CB_, NB_)                                                                                        \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_mfma_reconstruct<CB_>,                                \
+            TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_mfma_reconstruct<CB_, NB_>,                           \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_mfma_reconstruct<CB_>), dim3((unsigned)blocks), dim3(kBlock), pl.lds, s, g, pl.MB,   \
-                           pl.xblocks, pl.cgroups, W, H, R);                                                       \
+        hipLaunchKernelGGL((k_mfma_reconstruct<CB_, NB_>), dim3((unsigned)blocks), dim3(kBlock), pl.lds, s, g,     \
+                           pl.MB, pl.xblocks, pl.cgroups, ctx->ablate, W, H, R);                                   \
     } while (0)
-    switch (pl.CB) {
-        case 1: LAUNCH_RC(1); break;
-        case 2: LAUNCH_RC(2); break;
-        case 3: LAUNCH_RC(3); break;
-        default: LAUNCH_RC(4); break;
+#define LAUNCH_RC_NB(CB_)                 \
+    switch (nbq) {                        \
+        case 2: LAUNCH_RC(CB_, 2); break; \
+        case 3: LAUNCH_RC(CB_, 3); break; \
+        case 4: LAUNCH_RC(CB_, 4); break; \
+        default: LAUNCH_RC(CB_, 0); break;\
     }
+    const int nbq = ((g.Ax + 3) & ~3) >> 2;   // b-quads per atom: unrolled kernels for Ax in 5..16
+    switch (pl.CB) {   // the per-atom unrolled loop is instantiated for one channel only (register budget)
+        case 1: LAUNCH_RC_NB(1); break;
+        case 2: LAUNCH_RC(2, 0); break;
+        case 3: LAUNCH_RC(3, 0); break;
+        default: LAUNCH_RC(4, 0); break;
+    }
+#undef LAUNCH_RC_NB
 #undef LAUNCH_RC
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
@@ -769,7 +828,7 @@ int mfma_corr_H(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R,
     if (P != pl.cg.P) return TNMF_E_WORKSPACE;
     const dim3 grid(pl.cg.P, pl.MT, pl.JG);
 #define LAUNCH_CH(NT_) \
-    case NT_: hipLaunchKernelGGL((k_mfma_corr_H<NT_>), grid, dim3(kBlock), pl.lds, s, g, pl.cg, V, R, H, partials); break
+    case NT_: hipLaunchKernelGGL((k_mfma_corr_H<NT_>), grid, dim3(kBlock), pl.lds, s, g, pl.cg, ctx->ablate, V, R, H, partials); break
     switch (pl.NT) {
         LAUNCH_CH(1);
         LAUNCH_CH(2);
