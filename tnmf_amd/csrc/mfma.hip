@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
     const int ntail = TL ? (32 + lpi - 1) / lpi : 0;
     const int tl = TL ? lane / TL : 0, tc = TL ? lane - tl * TL : 0;
     const int xelems = g.C * plane;
-    const bool x_pref = xelems <= CH_XE * kBlock;
+    const bool x_pref = false;   // X windows are small: loaded in commit() (the second workgroup on the CU covers the latency); prefetching them costs 16+ VGPRs and an occupancy step
     float pm[32], pt[CH_MAXTAIL], pxv[CH_XE], pxr[CH_XE];
 
     auto item_coords = [&](int it, int &n, int &r0, int &t0) {
