@@ -142,8 +142,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     group = None
-    if world > 1:
+    force_dist = os.environ.get('TNMF_BENCH_FORCE_DIST') == '1'   # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)   # nccl == RCCL on ROCm
         group = dist.group.WORLD
 
@@ -174,7 +178,7 @@ def main():
         nmf._update_W()
 
     def fence():
-        if world > 1:
+        if group is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -190,7 +194,7 @@ def main():
     spans = be.stop_timeline()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if group is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     energy = nmf._energy_function()     # collective when sharded; outside the timed region
@@ -238,7 +242,7 @@ def main():
             line['cpu_baseline']['gpu_over_cpu'] = line['value'] / line['cpu_baseline']['value']
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

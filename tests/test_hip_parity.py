@@ -227,25 +227,38 @@ def test_f32_loop_parity_with_f64_oracle(N, C, D, M, A, path):
     assert abs(nmf._energy_function() - ref.energy()) / ref.energy() < 1e-5
 
 
-def test_matrix_core_kernels_are_dispatched():
-    """The float32 2-D shapes of the BASELINE configs must run on the MFMA kernels, not fall back silently."""
-    for (C, M, A) in ((1, 16, (9, 9)), (1, 32, (12, 12)), (3, 32, (12, 12)), (3, 64, (16, 16))):
-        rng = np.random.default_rng(0)
-        D = (40, 72)
-        V = rng.random((2, C) + D).astype(np.float32)
-        be = make_backend(V, A, M, 'mfma')        # 'mfma' = no generic fallback: unsupported shapes raise
-        W = dev(rng.random((M, C) + A), np.float32)
-        H = dev(rng.random((2, M) + tuple(d + a - 1 for d, a in zip(D, A))), np.float32)
+BASELINE_SHAPES = [
+    # C, D, M, A   -- the geometries of BASELINE.json configs 2..5 (one sample each)
+    (1, (128, 128), 16, (9, 9)),
+    (1, (256, 256), 32, (12, 12)),
+    (3, (256, 256), 32, (12, 12)),
+    (3, (512, 512), 64, (16, 16)),
+]
+
+
+@pytest.mark.parametrize('C,D,M,A', BASELINE_SHAPES, ids=['config2', 'config3', 'config4', 'config5'])
+def test_matrix_core_kernels_at_baseline_sizes(C, D, M, A):
+    """At the BASELINE geometries every primitive must run on the MFMA kernels (path='mfma' has no fallback) and agree
+    with the generic kernel family (an independent implementation, itself checked against the oracle above)."""
+    rng = np.random.default_rng(5)
+    V = rng.random((1, C) + D).astype(np.float32)
+    Wn = rng.random((M, C) + A).astype(np.float32)
+    Hn = rng.random((1, M) + tuple(d + a - 1 for d, a in zip(D, A))).astype(np.float32)
+    out = {}
+    for path in ('mfma', 'generic'):
+        be = make_backend(V, A, M, path)
+        W, H = dev(Wn, np.float32), dev(Hn, np.float32)
         R = be.reconstruct(W, H)
-        assert be.last_path == 'mfma'
-        be.reconstruction_gradient_H(V, W, H)
-        assert be.last_path == 'mfma'
-        neg, pos = be.reconstruction_gradient_W(V, W, H)
-        assert be.last_path == 'mfma'
-        Wn, Hn = be.to_ndarray(W).astype(np.float64), be.to_ndarray(H).astype(np.float64)
-        on, op = orc.gradient_W(V.astype(np.float64), Wn, Hn, slice(None), 'c')
-        assert relmax(be.to_ndarray(neg), on) < 2e-5 and relmax(be.to_ndarray(pos), op) < 2e-5
-        assert relmax(be.to_ndarray(R), orc.reconstruct(Wn, Hn, 'c')) < 2e-5
+        assert be.last_path == path
+        nH, pH = be.reconstruction_gradient_H(V, W, H)
+        assert be.last_path == path
+        nW, pW = be.reconstruction_gradient_W(V, W, H)
+        assert be.last_path == path
+        Hf = H.clone()
+        be.fused_update_H(V, W, Hf, slice(None), sparsity=0.05, eps=1e-9)
+        out[path] = [be.to_ndarray(x) for x in (R, nH, pH, nW, pW, Hf)]
+    for got, want in zip(out['mfma'], out['generic']):
+        assert relmax(got, want) < 2e-5
 
 
 def test_errors_like_the_reference():

@@ -223,6 +223,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
     const int j = lane & 15, kq = lane >> 4;
     const int nA = g.Ay * g.Ax;
     const int J = g.C * nA;
+    // only the channels this column group touches are staged: [c0, c0 + nch)
+    const int c0 = (jg * NT * 16) / nA;
+    int c1 = ((jg + 1) * NT * 16 - 1) / nA;
+    if (c1 > g.C - 1) c1 = g.C - 1;
+    const int nch = c1 - c0 + 1;
 
     int bo[NT];
 #pragma unroll
@@ -231,9 +236,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
         if (col < J) {
             const int c = col / nA, s = col - c * nA;
             const int a = s / g.Ax, b = s - a * g.Ax;
-            bo[t] = c * plane + (2 * kh + (g.Ay - 1) - a) * XST + (g.Ax - 1) - b + kq;
+            bo[t] = (c - c0) * plane + (2 * kh + (g.Ay - 1) - a) * XST + (g.Ax - 1) - b + kq;
         } else {
-            bo[t] = g.C * plane;
+            bo[t] = nch * plane;
         }
     }
 
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
         accv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         accr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int i = threadIdx.x; i < ZL; i += kBlock) Xs[g.C * plane + i] = float2{0.f, 0.f};
+    for (int i = threadIdx.x; i < ZL; i += kBlock) Xs[nch * plane + i] = float2{0.f, 0.f};
 
     // ---- staging map (fixed): H tile lines = (atom mi, row), line = mi*CH_RH + row, 128 lines; wave w stages lines
     // w, w+4, ...: columns 0..63 one per lane, columns 64..TW-1 packed lpi lines per instruction
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
     const int lpi = TL ? 64 / TL : 1;
     const int ntail = TL ? (32 + lpi - 1) / lpi : 0;
     const int tl = TL ? lane / TL : 0, tc = TL ? lane - tl * TL : 0;
-    const int xelems = g.C * plane;
+    const int xelems = nch * plane;
     const bool x_pref = false;   // X windows are small: loaded in commit() (the second workgroup on the CU covers the latency); prefetching them costs 16+ VGPRs and an occupancy step
     float pm[32], pt[CH_MAXTAIL], pxv[CH_XE], pxr[CH_XE];
 
@@ -267,8 +272,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
     // load itself is always legal (the value is masked when it is written to LDS)
     auto x_addr = [&](int i, int r0, int t0, unsigned &o) -> bool {   // o: element offset inside sample n
         const int ic = i < xelems ? i : 0;
-        const int c = ic / plane;
-        const int rem = ic - c * plane;
+        const int cl = ic / plane;
+        const int rem = ic - cl * plane;
+        const int c = c0 + cl;
         const int row = rem / XST, col = rem - row * XST;
         const int y = r0 - (g.Ay - 1) + row, x = t0 - (g.Ax - 1) + col;
         const bool in = i < xelems && y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
@@ -729,7 +735,15 @@ CorrHPlan plan_corr_H(const tnmf_hip_ctx *ctx, const Geo &g) {
     const int XST = cg.XSTW + g.Ax + 1;
     const size_t plane = (size_t)(CH_RH + g.Ay - 1) * XST;
     const size_t ZL = cg.TW + XST + 8;
-    const size_t stage = ((size_t)32 * cg.AST + 2 * ((size_t)g.C * plane + ZL)) * sizeof(float);   // (V,R) pairs
+    int nch_max = 1;   // most channels any column group touches
+    for (int jg = 0; jg < pl.JG; ++jg) {
+        const int nA = g.Ay * g.Ax;
+        const int c0 = (jg * pl.NT * 16) / nA;
+        int c1 = ((jg + 1) * pl.NT * 16 - 1) / nA;
+        if (c1 > g.C - 1) c1 = g.C - 1;
+        if (c1 - c0 + 1 > nch_max) nch_max = c1 - c0 + 1;
+    }
+    const size_t stage = ((size_t)32 * cg.AST + 2 * ((size_t)nch_max * plane + ZL)) * sizeof(float);   // (V,R) pairs
     const size_t red = (size_t)4 * 2 * 4 * 64 * sizeof(float);
     pl.lds = stage > red ? stage : red;
     return pl;
@@ -763,7 +777,7 @@ bool mfma_has_corr_H(const Geo &g, int dtype) {
     tnmf_hip_ctx fake{};
     fake.num_cu = 256;
     const CorrHPlan pl = plan_corr_H(&fake, g);
-    return pl.lds <= 64 * 1024 && pl.NT <= 12 && pl.cg.TW <= 72 && (pl.cg.TW <= 64 || (32 + 64 / (pl.cg.TW - 64) - 1) / (64 / (pl.cg.TW - 64)) <= CH_MAXTAIL);
+    return pl.lds <= 80 * 1024 && pl.NT <= 12 && pl.cg.TW <= 72 && (pl.cg.TW <= 64 || (32 + 64 / (pl.cg.TW - 64) - 1) / (64 / (pl.cg.TW - 64)) <= CH_MAXTAIL);
 }
 
 int mfma_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, const float *W, const float *H, float *R, hipStream_t s) {
@@ -827,8 +841,17 @@ int mfma_corr_H(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R,
     const CorrHPlan pl = plan_corr_H(ctx, g);
     if (P != pl.cg.P) return TNMF_E_WORKSPACE;
     const dim3 grid(pl.cg.P, pl.MT, pl.JG);
-#define LAUNCH_CH(NT_) \
-    case NT_: hipLaunchKernelGGL((k_mfma_corr_H<NT_>), grid, dim3(kBlock), pl.lds, s, g, pl.cg, ctx->ablate, V, R, H, partials); break
+#define LAUNCH_CH(NT_)                                                                                             \
+    case NT_: {                                                                                                    \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_mfma_corr_H<NT_>,                                     \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((k_mfma_corr_H<NT_>), grid, dim3(kBlock), pl.lds, s, g, pl.cg, ctx->ablate, V, R, H,    \
+                           partials);                                                                              \
+    } break
     switch (pl.NT) {
         LAUNCH_CH(1);
         LAUNCH_CH(2);
