@@ -130,6 +130,12 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
 
+    # Only the result line may reach stdout: libraries (the RCCL version banner, ...) write to fd 1 from C, so fd 1 is
+    # pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from tnmf_amd.TransformInvariantNMF import TransformInvariantNMF
@@ -240,7 +246,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_budget)
             line['cpu_baseline']['gpu_over_cpu'] = line['value'] / line['cpu_baseline']['value']
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
 
     if world > 1 or force_dist:
         dist.destroy_process_group()
