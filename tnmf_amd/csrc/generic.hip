@@ -247,23 +247,44 @@ __global__ __launch_bounds__(kBlock) void k_corr_H(Geo g, Tile t, int P, const T
 
 }  // namespace
 
-// stage 2 of every W gradient (generic and MFMA): sum the P partials in fixed order, in double; shift s of the
+// stage 2 of every W gradient (generic and MFMA): sum the P partials in double in a fixed order; shift s of the
 // partial layout is the *unflipped* offset (a', b') = (Ay-1-a, Ax-1-b), so the flip is a reversed linear index.
+// One block = 32 consecutive outputs x 8 interleaved p-slices (slice q sums p = q, q+8, ... in order), then the 8
+// slice sums are folded in order: the result does not depend on scheduling.
+constexpr int kFinOut = 32, kFinSlices = 8;
+
 template <typename T>
-__global__ void k_corr_H_finalize(int MC, int nA, int P, const double *__restrict__ partials, T *__restrict__ neg,
-                                  T *__restrict__ pos) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= MC * nA) return;
-    const int mc = i / nA, s = i - mc * nA;
+__global__ __launch_bounds__(kFinOut * kFinSlices) void k_corr_H_finalize(int MC, int nA, int P,
+                                                                            const double *__restrict__ partials,
+                                                                            T *__restrict__ neg, T *__restrict__ pos) {
+    __shared__ double sh[kFinSlices][kFinOut][2];
+    const int il = threadIdx.x % kFinOut, q = threadIdx.x / kFinOut;
+    const int i = blockIdx.x * kFinOut + il;
+    const int total = MC * nA;
     double sn = 0.0, sp = 0.0;
-    for (int p = 0; p < P; ++p) {
-        const double *in = partials + (((size_t)p * MC + mc) * nA + s) * 2;
-        sn += in[0];
-        sp += in[1];
+    if (i < total) {
+        const double2 *in = reinterpret_cast<const double2 *>(partials) + i;
+        for (int p = q; p < P; p += kFinSlices) {
+            const double2 v = in[(size_t)p * total];
+            sn += v.x;
+            sp += v.y;
+        }
     }
-    const size_t o = (size_t)mc * nA + (nA - 1 - s);
-    neg[o] = (T)sn;
-    pos[o] = (T)sp;
+    sh[q][il][0] = sn;
+    sh[q][il][1] = sp;
+    __syncthreads();
+    if (q == 0 && i < total) {
+        double tn = 0.0, tp = 0.0;
+#pragma unroll
+        for (int k = 0; k < kFinSlices; ++k) {
+            tn += sh[k][il][0];
+            tp += sh[k][il][1];
+        }
+        const int mc = i / nA, s = i - mc * nA;
+        const size_t o = (size_t)mc * nA + (nA - 1 - s);
+        neg[o] = (T)tn;
+        pos[o] = (T)tp;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -454,13 +475,13 @@ int generic_corr_H(tnmf_hip_ctx *, const Geo &g, int dtype, const void *V, const
 
 int finalize_corr_H(const Geo &g, int dtype, const double *partials, int P, void *neg, void *pos, hipStream_t s) {
     const int MC = g.M * g.C, nA = g.Ay * g.Ax;
-    const int blocks = cdiv(MC * nA, kBlock);
+    const int blocks = cdiv(MC * nA, kFinOut);
     if (dtype == 0)
-        hipLaunchKernelGGL(k_corr_H_finalize<float>, dim3(blocks), dim3(kBlock), 0, s, MC, nA, P, partials,
-                           (float *)neg, (float *)pos);
+        hipLaunchKernelGGL(k_corr_H_finalize<float>, dim3(blocks), dim3(kFinOut * kFinSlices), 0, s, MC, nA, P,
+                           partials, (float *)neg, (float *)pos);
     else
-        hipLaunchKernelGGL(k_corr_H_finalize<double>, dim3(blocks), dim3(kBlock), 0, s, MC, nA, P, partials,
-                           (double *)neg, (double *)pos);
+        hipLaunchKernelGGL(k_corr_H_finalize<double>, dim3(blocks), dim3(kFinOut * kFinSlices), 0, s, MC, nA, P,
+                           partials, (double *)neg, (double *)pos);
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
 }
