@@ -15,6 +15,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
 namespace {
 
@@ -25,6 +26,13 @@ __device__ __forceinline__ f32x16 zero16() {
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
     return z;
+}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory, i.e. it waits for every
+// outstanding global load/store of the wave (vmcnt(0)): prefetches and epilogue stores that are meant to stay in flight
+// across the barrier would be drained there.  Here only the LDS queue is drained; "memory" keeps hipcc from moving
+// memory operations across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -215,7 +223,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int nA = g.Ay * g.Ax;
-    const size_t mstride = (size_t)g.Hy * g.Hx;
 
     // W of this atom tile, all channels, once
     for (int i = threadIdx.x; i < g.C * KC * 32; i += kBlock) {
@@ -242,12 +249,20 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
         u0 = tyi * CP_TY;
         v0 = txi * CW_TX;
     };
-    // window element i -> (row, col); returns whether it lies inside the sample, o = clamped (legal) offset
-    auto x_addr = [&](int i, int u0, int v0, unsigned &o) -> bool {
+    // window elements of this thread: i = tid + 256 e, e < ne; their (row, col) never change, so they are computed once
+    const int ne = (welems + kBlock - 1) / kBlock;   // <= CP_XE
+    int wrc[CP_XE];                                  // row << 16 | col (element beyond the window: row 0, col 0)
+#pragma unroll
+    for (int e = 0; e < CP_XE; ++e) {
+        const int i = threadIdx.x + e * kBlock;
         const int ic = i < welems ? i : 0;
-        const int rr = ic / need_w, q = ic - rr * need_w;
-        const int y = u0 + rr - (g.Ay - 1), x = v0 + q - (g.Ax - 1);
-        const bool in = i < welems && y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
+        const int rr = ic / need_w;
+        wrc[e] = (rr << 16) | (ic - rr * need_w);
+    }
+    // returns whether element e lies inside the sample; o = clamped (always legal) offset inside the channel plane
+    auto x_addr = [&](int e, int u0, int v0, unsigned &o) -> bool {
+        const int y = u0 + (wrc[e] >> 16) - (g.Ay - 1), x = v0 + (wrc[e] & 0xffff) - (g.Ax - 1);
+        const bool in = y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
         const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1), xc = x < 0 ? 0 : (x < g.Dx ? x : g.Dx - 1);
         o = (unsigned)(yc * g.Dx + xc);
         return in;
@@ -259,10 +274,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
         const float *rp = Rr + ((size_t)n * g.C + c) * g.Dy * g.Dx;
 #pragma unroll
         for (int e = 0; e < CP_XE; ++e) {
-            unsigned o;
-            (void)x_addr(threadIdx.x + e * kBlock, u0, v0, o);
-            pxv[e] = vp[o];
-            pxr[e] = rp[o];
+            if (e < ne) {   // wave-uniform
+                unsigned o;
+                (void)x_addr(e, u0, v0, o);
+                pxv[e] = vp[o];
+                pxr[e] = rp[o];
+            }
         }
     };
     auto commit = [&](int st) {
@@ -270,12 +287,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
         stage_coords(st, n, u0, v0, c);
 #pragma unroll
         for (int e = 0; e < CP_XE; ++e) {
-            const int i = threadIdx.x + e * kBlock;
-            unsigned o;
-            const bool in = x_addr(i, u0, v0, o);
-            if (i < welems) {
-                const int rr = i / need_w, q = i - rr * need_w;
-                Xs[rr * CW_XSTR + q] = in ? float2{pxv[e], pxr[e]} : float2{0.f, 0.f};
+            if (e < ne) {
+                unsigned o;
+                const bool in = x_addr(e, u0, v0, o);
+                if (threadIdx.x + e * kBlock < welems)
+                    Xs[(wrc[e] >> 16) * CW_XSTR + (wrc[e] & 0xffff)] = in ? float2{pxv[e], pxr[e]} : float2{0.f, 0.f};
             }
         }
     };
@@ -297,24 +313,34 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
                 ap[rb] = zero16();
             }
         }
-        __syncthreads();   // every wave is done with the previous window (and, first time, W is staged)
+        lds_barrier();   // every wave is done with the previous window (and, first time, W is staged)
         if (!(ablate & 1)) commit(st);
-        __syncthreads();
+        lds_barrier();
         if (st + 1 < my_stages && !(ablate & 1)) prefetch(st + 1);
-        const int vv = v0 + j;
-        if (FUSED && c == g.C - 1 && !(ablate & 8)) {
-            // H values of this lane's 2 x 16 outputs: clamped (always legal) addresses, consumed only in the epilogue
-            const int vc = vv < g.Hx ? vv : g.Hx - 1;
+        // D = [pixel][atom] (A operand = window, B operand = W): lane (atom = lane&31, hl = lane>>5) holds, per
+        // accumulator, pixels 8q + 4hl + {0..3} in registers 4q..4q+3: four consecutive pixels of one atom = one 16-byte
+        // access.  (The [atom][pixel] orientation needs 4x as many 4-byte store instructions and is store-issue bound.)
+        const int atom = mt * 32 + j;
+        const int atomc = atom < g.M ? atom : g.M - 1;
+        const bool interior = v0 + CW_TX <= g.Hx;   // wave-uniform: whole tile inside the row
+        if (FUSED && c == g.C - 1 && !(ablate & (8 | 128))) {
+            // H values of this lane's outputs: clamped (always legal) addresses, consumed only in the epilogue
 #pragma unroll
             for (int rb = 0; rb < CP_RB; ++rb) {
                 const int u = u0 + wave * CP_RB + rb;
                 const int uc = u < g.Hy ? u : g.Hy - 1;
-                const float *hp = Hio + ((size_t)n * g.M * g.Hy + uc) * g.Hx + vc;
+                const float *hp = Hio + (((size_t)n * g.M + atomc) * g.Hy + uc) * g.Hx;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int m = mt * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                    m = m < g.M ? m : g.M - 1;
-                    hv[rb][r] = hp[(size_t)m * mstride];
+                for (int q = 0; q < 4; ++q) {
+                    const int p0 = v0 + 8 * q + 4 * h;
+                    if (interior) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4_u *>(hp + p0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[rb][4 * q + e] = t4[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[rb][4 * q + e] = hp[p0 + e < g.Hx ? p0 + e : g.Hx - 1];
+                    }
                 }
             }
         }
@@ -344,8 +370,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
 #define CP_MMA(w_, x_)                                        \
     do {                                                      \
         _Pragma("unroll") for (int rb = 0; rb < CP_RB; ++rb) { \
-            an[rb] = mfma32(w_, x_[rb].x, an[rb]);            \
-            ap[rb] = mfma32(w_, x_[rb].y, ap[rb]);            \
+            an[rb] = mfma32(x_[rb].x, w_, an[rb]);            \
+            ap[rb] = mfma32(x_[rb].y, w_, ap[rb]);            \
         }                                                     \
     } while (0)
         CP_LOAD(wA, xA);
@@ -364,22 +390,41 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
 #undef CP_NEXT
 #undef CP_MMA
 
-        if (c == g.C - 1 && vv < g.Hx && !(ablate & 8)) {
+        if (c == g.C - 1 && atom < g.M && !(ablate & (8 | 64))) {
 #pragma unroll
             for (int rb = 0; rb < CP_RB; ++rb) {
                 const int u = u0 + wave * CP_RB + rb;
                 if (u < g.Hy) {
-                    const size_t base = (((size_t)n * g.M + mt * 32 + 4 * h) * g.Hy + u) * g.Hx + vv;
+                    const size_t row = (((size_t)n * g.M + atom) * g.Hy + u) * g.Hx;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = (r & 3) + 8 * (r >> 2);
-                        if (mt * 32 + 4 * h + ml < g.M) {
+                    for (int q = 0; q < 4; ++q) {
+                        const int p0 = v0 + 8 * q + 4 * h;
+                        f32x4 o4, n4, q4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // H * neg / (pos + reg) with the hardware reciprocal (1 ulp): within the f32 parity budget
+                            o4[e] = __fdividef(hv[rb][4 * q + e] * an[rb][4 * q + e], ap[rb][4 * q + e] + reg);
+                            n4[e] = an[rb][4 * q + e];
+                            q4[e] = ap[rb][4 * q + e];
+                        }
+                        if (interior) {
                             if (FUSED) {
-                                Hio[base + ml * mstride] = (hv[rb][r] * an[rb][r]) / (ap[rb][r] + reg);
+                                *reinterpret_cast<f32x4_u *>(Hio + row + p0) = o4;
                             } else {
-                                neg[base + ml * mstride] = an[rb][r];
-                                pos[base + ml * mstride] = ap[rb][r];
+                                *reinterpret_cast<f32x4_u *>(neg + row + p0) = n4;
+                                *reinterpret_cast<f32x4_u *>(pos + row + p0) = q4;
                             }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (p0 + e < g.Hx) {
+                                    if (FUSED) {
+                                        Hio[row + p0 + e] = o4[e];
+                                    } else {
+                                        neg[row + p0 + e] = n4[e];
+                                        pos[row + p0 + e] = q4[e];
+                                    }
+                                }
                         }
                     }
                 }
@@ -750,7 +795,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
 
         for (int ch = 0; ch < nchunks; ++ch, ++stage) {
             const int m0 = ch * MB;
-            __syncthreads();   // every wave is done with the previous stage's tile
+            lds_barrier();   // every wave is done with the previous stage's tile (R stores stay in flight)
             if (nchunks > 1 || rb0 == 0) {
                 for (int i = threadIdx.x; i < CB * K4 * 16; i += kBlock) {
                     const int a = i & 15;
@@ -763,7 +808,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
                 }
             }
             if (!(ablate & 1)) commit(stage);
-            __syncthreads();
+            lds_barrier();
             if (stage + 1 < nstages && !(ablate & 1)) prefetch(stage + 1);   // in flight under the MFMAs below
 
             const float *wl = Wl + kq * 16 + j;
