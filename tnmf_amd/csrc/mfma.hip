@@ -11,6 +11,9 @@
 // Operand maps used (lane l of the wave64):
 //   32x32x2 : A[i = l&31][k = l>>5]   B[k = l>>5][j = l&31]   D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31], r = 0..15
 //   16x16x4 : A[i = l&15][k = l>>4]   B[k = l>>4][j = l&15]   D[row = 4*(l>>4) + r][col = l&15],           r = 0..3
+#include <cstdio>
+#include <cstdlib>
+
 #include "mfma.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,6 +34,20 @@ __device__ __forceinline__ f32x16 zero16() {
 // outstanding global load/store of the wave (vmcnt(0)): prefetches and epilogue stores that are meant to stay in flight
 // across the barrier would be drained there.  Here only the LDS queue is drained; "memory" keeps hipcc from moving
 // memory operations across the barrier.
+// diagnostic builds of the timing harness only (env TNMF_HIP_STAMPS): cycle stamp that also drains the LDS queue
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define STAMP(k_)                                   \
+    do {                                            \
+        if (dbg) {                                  \
+            const unsigned long long t_ = stamp();  \
+            phase[k_] += t_ - tprev;                \
+            tprev = t_;                             \
+        }                                           \
+    } while (0)
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -690,11 +707,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
 //   atom chunk of MB atoms (zero beyond Hy/Hx/M), Wf for the chunk as [c][k = (m,b)][16 rows], b padded to 4.
 // ================================================================================================================
 constexpr int RC_RBK = 4;
-constexpr int RC_MAXLPW = 32;    // (atom, row) lines staged per wave: MB * RC_RBK / 4 <= 32
-constexpr int RC_MAXTAIL = 16;   // packed tail loads per wave (tail = columns 64 .. 64+Axp4-1 of a line)
+constexpr int RC_NE4 = 12;       // 16-byte staging pieces per thread: 128 lines * (HST/4 <= 24) / 256
 
 template <int CB, int NB>
 __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, int xblocks, int cgroups, int ablate,
+                                                                unsigned long long *__restrict__ dbg,
                                                                 const float *__restrict__ W,
                                                                 const float *__restrict__ H, float *__restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -722,59 +739,71 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
     const int nrb = (rows_total + RC_RBK - 1) / RC_RBK;
     const int nstages = nrb * nchunks;
 
-    // ---- staging map of this thread (fixed over the sweep).  Lines = (atom ml, row) pairs, line = ml*RC_RBK + row;
-    // wave w stages lines w, w+4, ...: columns 0..63 one per lane ("main"), columns 64..HST-1 packed lpi lines per
-    // instruction ("tail").  The values of stage s+1 are fetched into registers while stage s is being multiplied.
-    const int lpi = 64 / Axp4;                       // lines per tail instruction
-    const int ntail = (MB + lpi - 1) / lpi;
-    const int tl = lane / Axp4, tc = lane - tl * Axp4;
-    const bool main_ok = x0 + lane < g.Hx;
-    const bool tail_ok = tl < lpi && x0 + 64 + tc < g.Hx;
-    const float *Hn = H + (size_t)n * g.M * g.Hy * g.Hx + x0;
-    float pm[RC_MAXLPW], pt[RC_MAXTAIL];
+    // ---- staging.  The stage tile [MB*RC_RBK lines][HST] (line = ml*RC_RBK + row) is walked flat in 16-byte pieces:
+    // piece f = tid + 256 e of thread tid is (line, 4 columns).  One dwordx4 load per piece: the address unit handles a
+    // wave instruction in ~16 cycles whatever its width, so 4-byte loads would quarter the staging rate (measured: issue
+    // of 39 dword loads per thread took 14 % and their landing another 20 % of the kernel).  Loads are unconditional on
+    // clamped, always legal addresses (rows are only 4-byte aligned: unaligned dwordx4 is fine on gfx950); the raw
+    // values of stage s+1 stay untouched in registers while stage s is multiplied and are masked (zero outside H /
+    // beyond M) when commit() writes them to LDS with one ds_write_b128 each.
+    const int q4 = HST >> 2;                          // pieces per line
+    const int nlines = MB * RC_RBK;
+    const int npiece = nlines * q4;
+    const int ne = (npiece + kBlock - 1) / kBlock;    // <= RC_NE4, wave-uniform
+    const bool edge = x0 + HST > g.Hx;                // this workgroup's window crosses the right border
+    const float *Hn = H + (size_t)n * g.M * g.Hy * g.Hx;
+    int plc[RC_NE4];                                  // line << 8 | piece column, fixed over the sweep
+#pragma unroll
+    for (int e = 0; e < RC_NE4; ++e) {
+        const int f = threadIdx.x + e * kBlock;
+        const int fc = f < npiece ? f : 0;
+        const int line = fc / q4;
+        plc[e] = (line << 8) | (fc - line * q4);
+    }
+    f32x4 pm[RC_NE4];
 
-    // line wave + 4q is (atom q of the chunk, row wave): one running pointer with the (opaque) atom stride
     auto prefetch = [&](int stage) {
         const int rb0 = (stage / nchunks) * RC_RBK;
         const int m0 = (stage % nchunks) * MB;
-        size_t astr = (size_t)g.Hy * g.Hx;
-        asm volatile("" : "+s"(astr));
-        const int r = rb0 + wave;
         int nat = g.M - m0;              // atoms of this chunk that exist (>= 1)
         if (nat > MB) nat = MB;
-        // loads are unconditional on clamped (always valid) addresses and zeroed afterwards: no branch per load
-        const int rc = r < g.Hy ? r : g.Hy - 1;
-        const unsigned lc = (unsigned)(main_ok ? lane : g.Hx - 1 - x0);
-        const unsigned tcc = (unsigned)(x0 + 64 + tc < g.Hx ? 64 + tc : g.Hx - 1 - x0);
-        const float *src = Hn + ((size_t)m0 * g.Hy + rc) * g.Hx;
-        // NB: the raw values stay untouched until commit() masks them, so nothing waits on these loads here; every
-        // address is a wave-uniform base (SGPRs) plus one shared 32-bit lane offset
 #pragma unroll
-        for (int q = 0; q < RC_MAXLPW; ++q) {
-            const float *sq_ = src + (size_t)(q < nat ? q : nat - 1) * astr;
-            pm[q] = sq_[lc];
-        }
-        const unsigned astr32 = (unsigned)astr;
-#pragma unroll
-        for (int i = 0; i < RC_MAXTAIL; ++i) {
-            const int q = i * lpi + tl;
-            if (i < ntail) pt[i] = src[(unsigned)(q < nat ? q : nat - 1) * astr32 + tcc];
+        for (int e = 0; e < RC_NE4; ++e) {
+            if (e < ne) {
+                const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
+                int ml = line >> 2, r = rb0 + (line & 3);
+                ml = ml < nat ? ml : nat - 1;
+                r = r < g.Hy ? r : g.Hy - 1;
+                int xs = x0 + col;
+                xs = xs < g.Hx - 4 ? xs : g.Hx - 4;   // keep the 4 columns inside the row
+                pm[e] = *reinterpret_cast<const f32x4_u *>(Hn + ((size_t)(m0 + ml) * g.Hy + r) * g.Hx + xs);
+            }
         }
     };
     auto commit = [&](int stage) {
-        const int r = (stage / nchunks) * RC_RBK + wave;
+        const int rb0 = (stage / nchunks) * RC_RBK;
         int nat = g.M - (stage % nchunks) * MB;
         if (nat > MB) nat = MB;
-        const bool mok = r < g.Hy && main_ok;
-        const bool tok = r < g.Hy && tail_ok;
-        float *dst = Hs + wave * HST;
 #pragma unroll
-        for (int q = 0; q < RC_MAXLPW; ++q)
-            if (q < MB) dst[q * RC_RBK * HST + lane] = (mok && q < nat) ? pm[q] : 0.f;
+        for (int e = 0; e < RC_NE4; ++e) {
+            if (e < ne) {
+                const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
+                const bool lok = (line >> 2) < nat && rb0 + (line & 3) < g.Hy;
+                f32x4 v = pm[e];
+                if (edge) {
+                    // the load started at min(x, Hx-4): shift the components back and zero the columns beyond the row
+                    const int xa = x0 + col;
+                    const int sh = xa - (xa < g.Hx - 4 ? xa : g.Hx - 4);
+                    const f32x4 t = v;
+                    v[0] = sh == 0 ? t[0] : sh == 1 ? t[1] : sh == 2 ? t[2] : t[3];
+                    v[1] = sh == 0 ? t[1] : sh == 1 ? t[2] : t[3];
+                    v[2] = sh == 0 ? t[2] : t[3];
 #pragma unroll
-        for (int i = 0; i < RC_MAXTAIL; ++i) {
-            const int q = i * lpi + tl;
-            if (i < ntail && tl < lpi && q < MB) dst[q * RC_RBK * HST + 64 + tc] = (tok && q < nat) ? pt[i] : 0.f;
+                    for (int k = 0; k < 4; ++k) v[k] = (xa + k < g.Hx) ? v[k] : 0.f;
+                }
+                if (!lok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (threadIdx.x + e * kBlock < npiece) *reinterpret_cast<f32x4 *>(Hs + line * HST + col) = v;
+            }
         }
     };
 
@@ -786,6 +815,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
 
     if (!(ablate & 1)) prefetch(0);
     int stage = 0;
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = dbg ? stamp() : 0ull;
     for (int rb0 = 0; rb0 < rows_total; rb0 += RC_RBK) {
         f32x4 acc[RC_RBK][CB];
 #pragma unroll
@@ -795,7 +825,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
 
         for (int ch = 0; ch < nchunks; ++ch, ++stage) {
             const int m0 = ch * MB;
+            STAMP(0);        // rest of the loop body (accumulator init, ...)
             lds_barrier();   // every wave is done with the previous stage's tile (R stores stay in flight)
+            STAMP(1);        // barrier 1
             if (nchunks > 1 || rb0 == 0) {
                 for (int i = threadIdx.x; i < CB * K4 * 16; i += kBlock) {
                     const int a = i & 15;
@@ -808,8 +840,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
                 }
             }
             if (!(ablate & 1)) commit(stage);
+            STAMP(2);        // W staging (first stage) + commit
             lds_barrier();
+            STAMP(3);        // barrier 2
             if (stage + 1 < nstages && !(ablate & 1)) prefetch(stage + 1);   // in flight under the MFMAs below
+            STAMP(4);        // prefetch issue
 
             const float *wl = Wl + kq * 16 + j;
             const float *hb = Hs + wave * 16 + j + kq;
@@ -832,16 +867,24 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
                     acc[rr][c] = mfma16(a_[q][c], b_[q][rr], acc[rr][c]);                                  \
     } while (0)
                 if (!(ablate & 4)) {
+                    // One scheduling region per two atoms: [load B | multiply A | load A' | multiply B].  The LDS reads
+                    // are independent of the MFMAs next to them, and the scheduler is told to alternate them one for
+                    // one: a wave issues in order, so reads placed in front of an MFMA block leave the matrix pipe idle
+                    // while they issue, whereas a read issued in the shadow of a running MFMA is free.
                     int ml = 0;
                     RCA_LOAD(aA, bA, 0);
                     while (ml + 2 <= MB) {
                         RCA_LOAD(aB, bB, ml + 1);
-                        __builtin_amdgcn_sched_barrier(0);
                         RCA_MMA(aA, bA);
                         ml += 2;
-                        if (ml < MB) RCA_LOAD(aA, bA, ml);
-                        __builtin_amdgcn_sched_barrier(0);
+                        const int mn = ml < MB ? ml : MB - 1;   // last round: a redundant (legal) reload
+                        RCA_LOAD(aA, bA, mn);
                         RCA_MMA(aB, bB);
+#pragma unroll
+                        for (int k = 0; k < 2 * NB * RC_RBK * CB; ++k) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                        }
                     }
                     if (ml < MB) RCA_MMA(aA, bA);
                 }
@@ -893,6 +936,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
             }
         }
 
+        STAMP(5);   // MFMA loop(s)
         // col2im along the row axis, rows of this block in order.  The ring is private to the wave and LDS operations
         // of one wave execute in program order, so the accumulate (ds_add_f32, no return) needs no wait before the
         // read of the finished row; only the compiler has to be kept from reordering them.
@@ -925,6 +969,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
             }
             asm volatile("" ::: "memory");
         }
+        STAMP(6);   // col2im + R stores
+    }
+    if (dbg && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 4 + wave) * 8 + k] = phase[k];
     }
 }
 
@@ -1033,6 +1082,9 @@ int mfma_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, const float *W, const floa
     const ReconPlan pl = plan_reconstruct(g);
     const size_t blocks = (size_t)g.N * pl.cgroups * pl.xblocks;
     if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
+    unsigned long long *dbg = nullptr;
+    static const bool want_stamps = getenv("TNMF_HIP_STAMPS") != nullptr;   // diagnostic only
+    if (want_stamps) TNMF_HIP_TRY(hipMalloc(&dbg, blocks * 4 * 8 * sizeof(unsigned long long)));
 #define LAUNCH_RC(CB_, NB_)                                                                                        \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
@@ -1041,8 +1093,9 @@ int mfma_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, const float *W, const floa
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_mfma_reconstruct<CB_, NB_>), dim3((unsigned)blocks), dim3(kBlock), pl.lds, s, g,     \
-                           pl.MB, pl.xblocks, pl.cgroups, ctx->ablate, W, H, R);                                   \
+        hipLaunchKernelGGL((k_mfma_reconstruct<CB_, NB_>), dim3((unsigned)blocks), dim3(kBlock),                   \
+                           pl.lds + ((ctx->ablate & 4096) ? 40 * 1024 : 0), s, g,                                  \
+                           pl.MB, pl.xblocks, pl.cgroups, ctx->ablate, dbg, W, H, R);                              \
     } while (0)
 #define LAUNCH_RC_NB(CB_)                 \
     switch (nbq) {                        \
@@ -1059,6 +1112,23 @@ int mfma_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, const float *W, const floa
         default: LAUNCH_RC(4, 0); break;
     }
 #undef LAUNCH_RC_NB
+    if (dbg) {
+        TNMF_HIP_TRY(hipStreamSynchronize(s));
+        const size_t nw = blocks * 4;
+        unsigned long long *hbuf = (unsigned long long *)malloc(nw * 8 * sizeof(unsigned long long));
+        TNMF_HIP_TRY(hipMemcpy(hbuf, dbg, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double sum[8] = {0};
+        for (size_t w = 0; w < nw; ++w)
+            for (int k = 0; k < 8; ++k) sum[k] += (double)hbuf[w * 8 + k];
+        static const char *names[8] = {"rest", "barrier1", "commit", "barrier2", "prefetch", "mfma", "col2im", "-"};
+        double tot = 0;
+        for (int k = 0; k < 7; ++k) tot += sum[k];
+        fprintf(stderr, "[stamps reconstruct] cycles per wave:");
+        for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.0f (%.1f%%)", names[k], sum[k] / nw, 100.0 * sum[k] / tot);
+        fprintf(stderr, " total %.0f\n", tot / nw);
+        free(hbuf);
+        TNMF_HIP_TRY(hipFree(dbg));
+    }
 #undef LAUNCH_RC
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
