@@ -462,8 +462,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
 //   Output: partials[p][m*C + c][s = a'*Ax + b'][{V, R}] in double (summed in fixed order by k_corr_H_finalize).
 // ================================================================================================================
 constexpr int CH_RH = 4;
-constexpr int CH_MAXTAIL = 8;   // packed tail loads per wave of the H tile (columns 64 .. TW-1)
-constexpr int CH_XE = 8;        // X-window elements prefetched per thread and array (else staged without prefetch)
+constexpr int CH_NE4 = 9;        // 16-byte staging pieces of the H tile per thread: 128 lines * (TW/4 <= 18) / 256
 
 struct CorrHGeom {
     int TW, AST, XSTW, rblocks, cblocks, P;
@@ -516,15 +515,22 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
     }
     for (int i = threadIdx.x; i < ZL; i += kBlock) Xs[nch * plane + i] = float2{0.f, 0.f};
 
-    // ---- staging map (fixed): H tile lines = (atom mi, row), line = mi*CH_RH + row, 128 lines; wave w stages lines
-    // w, w+4, ...: columns 0..63 one per lane, columns 64..TW-1 packed lpi lines per instruction
-    const int TL = TW > 64 ? TW - 64 : 0;
-    const int lpi = TL ? 64 / TL : 1;
-    const int ntail = TL ? (32 + lpi - 1) / lpi : 0;
-    const int tl = TL ? lane / TL : 0, tc = TL ? lane - tl * TL : 0;
-    const int xelems = nch * plane;
-    const bool x_pref = false;   // X windows are small: loaded in commit() (the second workgroup on the CU covers the latency); prefetching them costs 16+ VGPRs and an occupancy step
-    float pm[32], pt[CH_MAXTAIL], pxv[CH_XE], pxr[CH_XE];
+    // ---- staging in 16-byte pieces (the address unit handles a wave instruction in ~16 cycles whatever its width).
+    // H tile: 128 lines (atom mi, row) x TW/4 pieces, piece f = tid + 256 e of thread tid; loads are unconditional on
+    // clamped, always legal addresses (start column min(t, Hx-4)), the raw values of the NEXT item stay in registers
+    // while the current item is multiplied and are shifted/masked when commit() writes them to LDS.
+    const int q4 = TW >> 2;
+    const int npiece = 32 * CH_RH * q4;
+    const int ne = (npiece + kBlock - 1) / kBlock;   // <= CH_NE4, wave-uniform
+    int plc[CH_NE4];                                  // line << 8 | piece column, fixed
+#pragma unroll
+    for (int e = 0; e < CH_NE4; ++e) {
+        const int f = threadIdx.x + e * kBlock;
+        const int fc = f < npiece ? f : 0;
+        const int line = fc / q4;
+        plc[e] = (line << 8) | (fc - line * q4);
+    }
+    f32x4 pm[CH_NE4];
 
     auto item_coords = [&](int it, int &n, int &r0, int &t0) {
         const int cbi = it % cg.cblocks;
@@ -534,55 +540,21 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
         r0 = rbi * CH_RH;
         t0 = cbi * TW;
     };
-    // X-window element i of an item: returns whether it lies inside the sample; the address is clamped so that the
-    // load itself is always legal (the value is masked when it is written to LDS)
-    auto x_addr = [&](int i, int r0, int t0, unsigned &o) -> bool {   // o: element offset inside sample n
-        const int ic = i < xelems ? i : 0;
-        const int cl = ic / plane;
-        const int rem = ic - cl * plane;
-        const int c = c0 + cl;
-        const int row = rem / XST, col = rem - row * XST;
-        const int y = r0 - (g.Ay - 1) + row, x = t0 - (g.Ax - 1) + col;
-        const bool in = i < xelems && y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
-        const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1), xc = x < 0 ? 0 : (x < g.Dx ? x : g.Dx - 1);
-        o = (unsigned)((c * g.Dy + yc) * g.Dx + xc);
-        return in;
-    };
-    // line wave + 4q of the tile is (atom q, row wave): one running pointer with the atom stride, which is made
-    // opaque per item so that the compiler recomputes its multiples in the scalar unit instead of keeping them live
     auto prefetch = [&](int it) {
         int n, r0, t0;
         item_coords(it, n, r0, t0);
-        size_t astr = (size_t)g.Hy * g.Hx;
-        asm volatile("" : "+s"(astr));
-        const int r = r0 + wave;
         const int nat = g.M - mt * 32;   // atoms of this tile that exist (>= 1)
-        // loads are unconditional on clamped (always valid) addresses and masked at commit: no branch per load, and
-        // every address is a wave-uniform base (SGPRs) plus one shared 32-bit lane offset (saddr + voffset form)
-        const int rc = r < g.Hy ? r : g.Hy - 1;
-        const unsigned lc = (unsigned)(t0 + lane < g.Hx ? lane : g.Hx - 1 - t0);
-        const float *src = H + (((size_t)n * g.M + mt * 32) * g.Hy + rc) * g.Hx + t0;
+        const float *Hn = H + ((size_t)n * g.M + mt * 32) * g.Hy * g.Hx;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const float *sq_ = src + (size_t)(q < nat ? q : nat - 1) * astr;
-            pm[q] = sq_[lc];
-        }
-        const unsigned tcc = (unsigned)(t0 + 64 + tc < g.Hx ? 64 + tc : g.Hx - 1 - t0);
-        const unsigned astr32 = (unsigned)astr;
-#pragma unroll
-        for (int i = 0; i < CH_MAXTAIL; ++i) {
-            const int q = i * lpi + tl;
-            if (i < ntail) pt[i] = src[(unsigned)(q < nat ? q : nat - 1) * astr32 + tcc];
-        }
-        if (x_pref) {
-            const float *Vn = V + (size_t)n * g.C * g.Dy * g.Dx;
-            const float *Rn = Rr + (size_t)n * g.C * g.Dy * g.Dx;
-#pragma unroll
-            for (int e = 0; e < CH_XE; ++e) {
-                unsigned o;
-                (void)x_addr(threadIdx.x + e * kBlock, r0, t0, o);
-                pxv[e] = Vn[o];
-                pxr[e] = Rn[o];
+        for (int e = 0; e < CH_NE4; ++e) {
+            if (e < ne) {
+                const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
+                int mi = line >> 2, r = r0 + (line & 3);
+                mi = mi < nat ? mi : nat - 1;
+                r = r < g.Hy ? r : g.Hy - 1;
+                int xs = t0 + col;
+                xs = xs < g.Hx - 4 ? xs : g.Hx - 4;
+                pm[e] = *reinterpret_cast<const f32x4_u *>(Hn + ((size_t)mi * g.Hy + r) * g.Hx + xs);
             }
         }
     };
@@ -590,32 +562,57 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
         int n_, r0_, t0_;
         item_coords(it, n_, r0_, t0_);
         const int nat = g.M - mt * 32;
-        const bool mok = r0_ + wave < g.Hy && t0_ + lane < g.Hx;
-        const bool tok = r0_ + wave < g.Hy && t0_ + 64 + tc < g.Hx;
-        float *dst = Hs + wave * TW;
+        const bool edge = t0_ + TW > g.Hx;
 #pragma unroll
-        for (int q = 0; q < 32; ++q)
-            if (lane < TW) dst[q * AST + lane] = (mok && q < nat) ? pm[q] : 0.f;
+        for (int e = 0; e < CH_NE4; ++e) {
+            if (e < ne) {
+                const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
+                const bool lok = (line >> 2) < nat && r0_ + (line & 3) < g.Hy;
+                f32x4 v = pm[e];
+                if (edge) {
+                    const int xa = t0_ + col;
+                    const int sh = xa - (xa < g.Hx - 4 ? xa : g.Hx - 4);
+                    const f32x4 t = v;
+                    v[0] = sh == 0 ? t[0] : sh == 1 ? t[1] : sh == 2 ? t[2] : t[3];
+                    v[1] = sh == 0 ? t[1] : sh == 1 ? t[2] : t[3];
+                    v[2] = sh == 0 ? t[2] : t[3];
 #pragma unroll
-        for (int i = 0; i < CH_MAXTAIL; ++i) {
-            const int q = i * lpi + tl;
-            if (i < ntail && tl < lpi && q < 32) dst[q * AST + 64 + tc] = (tok && q < nat) ? pt[i] : 0.f;
-        }
-        if (x_pref) {
-#pragma unroll
-            for (int e = 0; e < CH_XE; ++e) {
-                const int i = threadIdx.x + e * kBlock;
-                unsigned o;
-                const bool in = x_addr(i, r0_, t0_, o);
-                if (i < xelems) Xs[i] = in ? float2{pxv[e], pxr[e]} : float2{0.f, 0.f};
+                    for (int k = 0; k < 4; ++k) v[k] = (xa + k < g.Hx) ? v[k] : 0.f;
+                }
+                if (!lok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (threadIdx.x + e * kBlock < npiece) {
+                    // the atom stride is only 8-byte aligned (== 2 mod 32 words): two 8-byte stores
+                    float2 *dst = reinterpret_cast<float2 *>(Hs + (line >> 2) * AST + (line & 3) * TW + col);
+                    dst[0] = float2{v[0], v[1]};
+                    dst[1] = float2{v[2], v[3]};
+                }
             }
-        } else {
-            const float *Vn = V + (size_t)n_ * g.C * g.Dy * g.Dx;
-            const float *Rn = Rr + (size_t)n_ * g.C * g.Dy * g.Dx;
-            for (int i = threadIdx.x; i < xelems; i += kBlock) {
-                unsigned o;
-                const bool in = x_addr(i, r0_, t0_, o);
-                Xs[i] = in ? float2{Vn[o], Rn[o]} : float2{0.f, 0.f};
+        }
+        // (V, R) windows of the channels of this column group: rows r0-(Ay-1) .. r0+RH-1, columns t0-(Ax-1) .. in pieces
+        // of 4; loaded here (small, L2-resident; the second workgroup of the CU covers the latency)
+        const int xq4 = (TW + g.Ax - 1 + 3) >> 2;
+        const int nxp = nch * XR * xq4;
+        for (int i = threadIdx.x; i < nxp; i += kBlock) {
+            const int c4 = i % xq4;
+            const int row = (i / xq4) % XR;
+            const int cl = i / (xq4 * XR);
+            const int y = r0_ - (g.Ay - 1) + row;
+            const int xa = t0_ - (g.Ax - 1) + 4 * c4;
+            const bool yok = y >= 0 && y < g.Dy;
+            const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1);
+            int xs = xa < 0 ? 0 : xa;
+            xs = xs < g.Dx - 4 ? xs : g.Dx - 4;
+            const size_t o = (((size_t)n_ * g.C + c0 + cl) * g.Dy + yc) * g.Dx + xs;
+            const f32x4 tv = *reinterpret_cast<const f32x4_u *>(V + o);
+            const f32x4 tr = *reinterpret_cast<const f32x4_u *>(Rr + o);
+            float2 *dst = Xs + cl * plane + row * XST + 4 * c4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = xa + k, d = x - xs;   // d in 0..3 whenever x is inside the row
+                const bool ok = yok && x >= 0 && x < g.Dx;
+                const float vv = d == 0 ? tv[0] : d == 1 ? tv[1] : d == 2 ? tv[2] : tv[3];
+                const float rr = d == 0 ? tr[0] : d == 1 ? tr[1] : d == 2 ? tr[2] : tr[3];
+                dst[k] = ok ? float2{vv, rr} : float2{0.f, 0.f};
             }
         }
     };
@@ -1075,7 +1072,7 @@ bool mfma_has_corr_H(const Geo &g, int dtype) {
     tnmf_hip_ctx fake{};
     fake.num_cu = 256;
     const CorrHPlan pl = plan_corr_H(&fake, g);
-    return pl.lds <= 80 * 1024 && pl.NT <= 12 && pl.cg.TW <= 72 && (pl.cg.TW <= 64 || (32 + 64 / (pl.cg.TW - 64) - 1) / (64 / (pl.cg.TW - 64)) <= CH_MAXTAIL);
+    return pl.lds <= 80 * 1024 && pl.NT <= 12 && pl.cg.TW <= 72 && g.Hx >= 4 && g.Dx >= 4;
 }
 
 int mfma_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, const float *W, const float *H, float *R, hipStream_t s) {
