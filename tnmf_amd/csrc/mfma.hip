@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
 //   update: the 4.7 GB read-modify-write of H per call then hides under the matrix pipe instead of serialising
 //   memory round trips at the end of every tile (measured 1.0 of 3.9 ms in the one-tile-per-workgroup kernel).
 // ================================================================================================================
-constexpr int CP_TY = 8, CP_RB = 2, CP_XE = 10;   // CP_XE: window elements prefetched per thread (39 x 63 / 256)
+constexpr int CP_TY = 8, CP_RB = 2, CP_XE4 = 3;   // CP_XE4: 4-column window pieces prefetched per thread (39 x 16 / 256)
 
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int tiles_y, int tiles_x, int ablate,
@@ -231,7 +231,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
     const int SH = CP_TY + g.Ay - 1;
     const int KC = g.Ay * Axp;
     const int need_w = CW_TX + Axp - 1;
-    const int welems = SH * need_w;
     float2 *Xs = reinterpret_cast<float2 *>(smem);   // [SH][CW_XSTR] of (V, R)
     float *Ws = smem + 2 * SH * CW_XSTR;             // [C][KC][32]
 
@@ -254,7 +253,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
 
     const int ntiles = g.N * tiles_y * tiles_x;
     const int nstages = ntiles * g.C;
-    float pxv[CP_XE], pxr[CP_XE];
+    f32x4 pxv[CP_XE4], pxr[CP_XE4];
 
     auto stage_coords = [&](int st, int &n, int &u0, int &v0, int &c) {
         c = st % g.C;
@@ -266,36 +265,32 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
         u0 = tyi * CP_TY;
         v0 = txi * CW_TX;
     };
-    // window elements of this thread: i = tid + 256 e, e < ne; their (row, col) never change, so they are computed once
-    const int ne = (welems + kBlock - 1) / kBlock;   // <= CP_XE
-    int wrc[CP_XE];                                  // row << 16 | col (element beyond the window: row 0, col 0)
+    // window pieces (4 columns = one dwordx4 load per array) of this thread: p = tid + 256 e, e < ne; (row, piece) fixed
+    const int wq4 = (need_w + 3) >> 2;
+    const int wpieces = SH * wq4;
+    const int ne = (wpieces + kBlock - 1) / kBlock;   // <= CP_XE4
+    int wrc[CP_XE4];                                  // row << 16 | first column
 #pragma unroll
-    for (int e = 0; e < CP_XE; ++e) {
+    for (int e = 0; e < CP_XE4; ++e) {
         const int i = threadIdx.x + e * kBlock;
-        const int ic = i < welems ? i : 0;
-        const int rr = ic / need_w;
-        wrc[e] = (rr << 16) | (ic - rr * need_w);
+        const int ic = i < wpieces ? i : 0;
+        const int rr = ic / wq4;
+        wrc[e] = (rr << 16) | ((ic - rr * wq4) << 2);
     }
-    // returns whether element e lies inside the sample; o = clamped (always legal) offset inside the channel plane
-    auto x_addr = [&](int e, int u0, int v0, unsigned &o) -> bool {
-        const int y = u0 + (wrc[e] >> 16) - (g.Ay - 1), x = v0 + (wrc[e] & 0xffff) - (g.Ax - 1);
-        const bool in = y >= 0 && y < g.Dy && x >= 0 && x < g.Dx;
-        const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1), xc = x < 0 ? 0 : (x < g.Dx ? x : g.Dx - 1);
-        o = (unsigned)(yc * g.Dx + xc);
-        return in;
-    };
     auto prefetch = [&](int st) {
         int n, u0, v0, c;
         stage_coords(st, n, u0, v0, c);
         const float *vp = V + ((size_t)n * g.C + c) * g.Dy * g.Dx;
         const float *rp = Rr + ((size_t)n * g.C + c) * g.Dy * g.Dx;
 #pragma unroll
-        for (int e = 0; e < CP_XE; ++e) {
+        for (int e = 0; e < CP_XE4; ++e) {
             if (e < ne) {   // wave-uniform
-                unsigned o;
-                (void)x_addr(e, u0, v0, o);
-                pxv[e] = vp[o];
-                pxr[e] = rp[o];
+                const int y = u0 + (wrc[e] >> 16) - (g.Ay - 1), xa = v0 + (wrc[e] & 0xffff) - (g.Ax - 1);
+                const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1);
+                int xs = xa < 0 ? 0 : xa;
+                xs = xs < g.Dx - 4 ? xs : g.Dx - 4;   // clamped, always legal start column
+                pxv[e] = *reinterpret_cast<const f32x4_u *>(vp + (size_t)yc * g.Dx + xs);
+                pxr[e] = *reinterpret_cast<const f32x4_u *>(rp + (size_t)yc * g.Dx + xs);
             }
         }
     };
@@ -303,12 +298,25 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
         int n, u0, v0, c;
         stage_coords(st, n, u0, v0, c);
 #pragma unroll
-        for (int e = 0; e < CP_XE; ++e) {
+        for (int e = 0; e < CP_XE4; ++e) {
             if (e < ne) {
-                unsigned o;
-                const bool in = x_addr(e, u0, v0, o);
-                if (threadIdx.x + e * kBlock < welems)
-                    Xs[(wrc[e] >> 16) * CW_XSTR + (wrc[e] & 0xffff)] = in ? float2{pxv[e], pxr[e]} : float2{0.f, 0.f};
+                const int rr = wrc[e] >> 16, q = wrc[e] & 0xffff;
+                const int y = u0 + rr - (g.Ay - 1), xa = v0 + q - (g.Ax - 1);
+                const bool yok = y >= 0 && y < g.Dy;
+                int xs = xa < 0 ? 0 : xa;
+                xs = xs < g.Dx - 4 ? xs : g.Dx - 4;
+                const f32x4 tv = pxv[e], tr = pxr[e];
+                if (threadIdx.x + e * kBlock < wpieces) {
+                    float2 *dst = Xs + rr * CW_XSTR + q;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int x = xa + k, d = x - xs;   // d in 0..3 whenever x lies inside the row
+                        const bool ok = yok && x >= 0 && x < g.Dx;
+                        const float vv = d == 0 ? tv[0] : d == 1 ? tv[1] : d == 2 ? tv[2] : tv[3];
+                        const float rv = d == 0 ? tr[0] : d == 1 ? tr[1] : d == 2 ? tr[2] : tr[3];
+                        dst[k] = ok ? float2{vv, rv} : float2{0.f, 0.f};
+                    }
+                }
             }
         }
     };
@@ -1138,8 +1146,8 @@ int mfma_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R,
         const int Axp = (g.Ax + 1) & ~1;
         const int SH = CP_TY + g.Ay - 1;
         const size_t lds_p = ((size_t)2 * SH * CW_XSTR + (size_t)g.C * g.Ay * Axp * 32) * sizeof(float);
-        const int welems = SH * (CW_TX + Axp - 1);
-        if (lds_p <= 52 * 1024 && welems <= CP_XE * kBlock && !(ctx->ablate & 32)) {
+        const int wpieces = SH * ((CW_TX + Axp - 1 + 3) / 4);
+        if (lds_p <= 52 * 1024 && wpieces <= CP_XE4 * kBlock && g.Dx >= 4 && !(ctx->ablate & 32)) {
             const int tiles_y = cdiv(g.Hy, CP_TY), tiles_x = cdiv(g.Hx, CW_TX), MT = cdiv(g.M, 32);
             const long ntiles = (long)g.N * tiles_y * tiles_x;
             if (ntiles > 0x7fffffffL) return TNMF_E_GEOM;
