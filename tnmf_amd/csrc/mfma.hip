@@ -989,7 +989,12 @@ struct ReconPlan {
 
 ReconPlan plan_reconstruct(const Geo &g) {
     ReconPlan pl;
-    pl.CB = g.C < 4 ? g.C : 4;
+    // One channel per workgroup when the per-atom unrolled kernel exists (Ax in 5..16): H is then read once per channel,
+    // which is cheap next to the matrix work, and the unrolled single-channel loop is the fastest form (config 4:
+    // 6.8 ms instead of 9.6 ms with three channels per workgroup; config 5 with two atom chunks: 63 vs 51 ms, so only
+    // for M <= 32).  Otherwise up to 4 channels share the H tile.
+    const int nbq = ((g.Ax + 3) & ~3) >> 2;
+    pl.CB = (nbq >= 2 && nbq <= 4 && g.M <= 32) ? 1 : (g.C < 4 ? g.C : 4);   // several atom chunks: share the W restaging
     pl.cgroups = cdiv(g.C, pl.CB);
     pl.xblocks = cdiv(g.Dx, 64);
     const int Axp4 = (g.Ax + 3) & ~3;
