@@ -857,11 +857,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
                 // k loop atom by atom, the NB b-quads of an atom fully unrolled (compile-time LDS offsets); operands of
                 // atom ml+1 (NB*CB + NB*RC_RBK reads) are fetched while the NB*RC_RBK*CB MFMAs of atom ml run
                 float aA[NB > 0 ? NB : 1][CB], bA[NB > 0 ? NB : 1][RC_RBK], aB[NB > 0 ? NB : 1][CB], bB[NB > 0 ? NB : 1][RC_RBK];
+                // compile-time row stride of the stage tile: every LDS offset inside an atom is an immediate, the only
+                // address arithmetic left is one add per atom and operand (the loop is issue-bound otherwise: 0.8 VALU
+                // adds + 0.9 LDS reads per 32-cycle MFMA measured before)
+                constexpr int HSTc = 64 + 4 * NB;
 #define RCA_LOAD(a_, b_, ML)                                                                               \
     do {                                                                                                   \
+        const float *wa_ = wl + (ML) * (NB * 64);                                                          \
+        const float *ha_ = hb + (ML) * (RC_RBK * HSTc);                                                    \
         _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                   \
-            _Pragma("unroll") for (int c = 0; c < CB; ++c) a_[q][c] = wl[(c * K4 + ((ML) * NB + q) * 4) * 16]; \
-            _Pragma("unroll") for (int rr = 0; rr < RC_RBK; ++rr) b_[q][rr] = hb[((ML) * RC_RBK + rr) * HST + 4 * q]; \
+            _Pragma("unroll") for (int c = 0; c < CB; ++c) a_[q][c] = wa_[c * K4 * 16 + q * 64];           \
+            _Pragma("unroll") for (int rr = 0; rr < RC_RBK; ++rr) b_[q][rr] = ha_[rr * HSTc + 4 * q];      \
         }                                                                                                  \
     } while (0)
 #define RCA_MMA(a_, b_)                                                                                    \
