@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
 // ================================================================================================================
 constexpr int CP_TY = 8, CP_RB = 2, CP_XE4 = 3;   // CP_XE4: 4-column window pieces prefetched per thread (39 x 16 / 256)
 
-template <bool FUSED>
+template <bool FUSED, int NE>
 __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int tiles_y, int tiles_x, int ablate,
                                                                    const float *__restrict__ V,
                                                                    const float *__restrict__ Rr,
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
 
     const int ntiles = g.N * tiles_y * tiles_x;
     const int nstages = ntiles * g.C;
-    f32x4 pxv[CP_XE4], pxr[CP_XE4];
+    f32x4 pxv[NE], pxr[NE];
 
     auto stage_coords = [&](int st, int &n, int &u0, int &v0, int &c) {
         c = st % g.C;
@@ -265,13 +265,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
         u0 = tyi * CP_TY;
         v0 = txi * CW_TX;
     };
-    // window pieces (4 columns = one dwordx4 load per array) of this thread: p = tid + 256 e, e < ne; (row, piece) fixed
+    // window pieces (4 columns = one dwordx4 load per array) of this thread: p = tid + 256 e, e < NE (compile time: the
+    // loads are unconditional so that hipcc can count what is in flight); (row, first column) never change
     const int wq4 = (need_w + 3) >> 2;
     const int wpieces = SH * wq4;
-    const int ne = (wpieces + kBlock - 1) / kBlock;   // <= CP_XE4
-    int wrc[CP_XE4];                                  // row << 16 | first column
+    int wrc[NE];                                      // row << 16 | first column
 #pragma unroll
-    for (int e = 0; e < CP_XE4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int i = threadIdx.x + e * kBlock;
         const int ic = i < wpieces ? i : 0;
         const int rr = ic / wq4;
@@ -283,39 +283,35 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
         const float *vp = V + ((size_t)n * g.C + c) * g.Dy * g.Dx;
         const float *rp = Rr + ((size_t)n * g.C + c) * g.Dy * g.Dx;
 #pragma unroll
-        for (int e = 0; e < CP_XE4; ++e) {
-            if (e < ne) {   // wave-uniform
-                const int y = u0 + (wrc[e] >> 16) - (g.Ay - 1), xa = v0 + (wrc[e] & 0xffff) - (g.Ax - 1);
-                const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1);
-                int xs = xa < 0 ? 0 : xa;
-                xs = xs < g.Dx - 4 ? xs : g.Dx - 4;   // clamped, always legal start column
-                pxv[e] = *reinterpret_cast<const f32x4_u *>(vp + (size_t)yc * g.Dx + xs);
-                pxr[e] = *reinterpret_cast<const f32x4_u *>(rp + (size_t)yc * g.Dx + xs);
-            }
+        for (int e = 0; e < NE; ++e) {
+            const int y = u0 + (wrc[e] >> 16) - (g.Ay - 1), xa = v0 + (wrc[e] & 0xffff) - (g.Ax - 1);
+            const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1);
+            int xs = xa < 0 ? 0 : xa;
+            xs = xs < g.Dx - 4 ? xs : g.Dx - 4;   // clamped, always legal start column
+            pxv[e] = *reinterpret_cast<const f32x4_u *>(vp + (size_t)yc * g.Dx + xs);
+            pxr[e] = *reinterpret_cast<const f32x4_u *>(rp + (size_t)yc * g.Dx + xs);
         }
     };
     auto commit = [&](int st) {
         int n, u0, v0, c;
         stage_coords(st, n, u0, v0, c);
 #pragma unroll
-        for (int e = 0; e < CP_XE4; ++e) {
-            if (e < ne) {
-                const int rr = wrc[e] >> 16, q = wrc[e] & 0xffff;
-                const int y = u0 + rr - (g.Ay - 1), xa = v0 + q - (g.Ax - 1);
-                const bool yok = y >= 0 && y < g.Dy;
-                int xs = xa < 0 ? 0 : xa;
-                xs = xs < g.Dx - 4 ? xs : g.Dx - 4;
-                const f32x4 tv = pxv[e], tr = pxr[e];
-                if (threadIdx.x + e * kBlock < wpieces) {
-                    float2 *dst = Xs + rr * CW_XSTR + q;
+        for (int e = 0; e < NE; ++e) {
+            const int rr = wrc[e] >> 16, q = wrc[e] & 0xffff;
+            const int y = u0 + rr - (g.Ay - 1), xa = v0 + q - (g.Ax - 1);
+            const bool yok = y >= 0 && y < g.Dy;
+            int xs = xa < 0 ? 0 : xa;
+            xs = xs < g.Dx - 4 ? xs : g.Dx - 4;
+            const f32x4 tv = pxv[e], tr = pxr[e];
+            if (threadIdx.x + e * kBlock < wpieces) {
+                float2 *dst = Xs + rr * CW_XSTR + q;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int x = xa + k, d = x - xs;   // d in 0..3 whenever x lies inside the row
-                        const bool ok = yok && x >= 0 && x < g.Dx;
-                        const float vv = d == 0 ? tv[0] : d == 1 ? tv[1] : d == 2 ? tv[2] : tv[3];
-                        const float rv = d == 0 ? tr[0] : d == 1 ? tr[1] : d == 2 ? tr[2] : tr[3];
-                        dst[k] = ok ? float2{vv, rv} : float2{0.f, 0.f};
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    const int x = xa + k, d = x - xs;   // d in 0..3 whenever x lies inside the row
+                    const bool ok = yok && x >= 0 && x < g.Dx;
+                    const float vv = d == 0 ? tv[0] : d == 1 ? tv[1] : d == 2 ? tv[2] : tv[3];
+                    const float rv = d == 0 ? tr[0] : d == 1 ? tr[1] : d == 2 ? tr[2] : tr[3];
+                    dst[k] = ok ? float2{vv, rv} : float2{0.f, 0.f};
                 }
             }
         }
@@ -529,7 +525,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
     // while the current item is multiplied and are shifted/masked when commit() writes them to LDS.
     const int q4 = TW >> 2;
     const int npiece = 32 * CH_RH * q4;
-    const int ne = (npiece + kBlock - 1) / kBlock;   // <= CH_NE4, wave-uniform
     int plc[CH_NE4];                                  // line << 8 | piece column, fixed
 #pragma unroll
     for (int e = 0; e < CH_NE4; ++e) {
@@ -554,16 +549,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
         const int nat = g.M - mt * 32;   // atoms of this tile that exist (>= 1)
         const float *Hn = H + ((size_t)n * g.M + mt * 32) * g.Hy * g.Hx;
 #pragma unroll
-        for (int e = 0; e < CH_NE4; ++e) {
-            if (e < ne) {
-                const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
-                int mi = line >> 2, r = r0 + (line & 3);
-                mi = mi < nat ? mi : nat - 1;
-                r = r < g.Hy ? r : g.Hy - 1;
-                int xs = t0 + col;
-                xs = xs < g.Hx - 4 ? xs : g.Hx - 4;
-                pm[e] = *reinterpret_cast<const f32x4_u *>(Hn + ((size_t)mi * g.Hy + r) * g.Hx + xs);
-            }
+        for (int e = 0; e < CH_NE4; ++e) {   // unconditional: pieces beyond the tile are clamped to piece 0
+            const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
+            int mi = line >> 2, r = r0 + (line & 3);
+            mi = mi < nat ? mi : nat - 1;
+            r = r < g.Hy ? r : g.Hy - 1;
+            int xs = t0 + col;
+            xs = xs < g.Hx - 4 ? xs : g.Hx - 4;
+            pm[e] = *reinterpret_cast<const f32x4_u *>(Hn + ((size_t)mi * g.Hy + r) * g.Hx + xs);
         }
     };
     auto commit = [&](int it) {
@@ -573,27 +566,25 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
         const bool edge = t0_ + TW > g.Hx;
 #pragma unroll
         for (int e = 0; e < CH_NE4; ++e) {
-            if (e < ne) {
-                const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
-                const bool lok = (line >> 2) < nat && r0_ + (line & 3) < g.Hy;
-                f32x4 v = pm[e];
-                if (edge) {
-                    const int xa = t0_ + col;
-                    const int sh = xa - (xa < g.Hx - 4 ? xa : g.Hx - 4);
-                    const f32x4 t = v;
-                    v[0] = sh == 0 ? t[0] : sh == 1 ? t[1] : sh == 2 ? t[2] : t[3];
-                    v[1] = sh == 0 ? t[1] : sh == 1 ? t[2] : t[3];
-                    v[2] = sh == 0 ? t[2] : t[3];
+            const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
+            const bool lok = (line >> 2) < nat && r0_ + (line & 3) < g.Hy;
+            f32x4 v = pm[e];
+            if (edge) {
+                const int xa = t0_ + col;
+                const int sh = xa - (xa < g.Hx - 4 ? xa : g.Hx - 4);
+                const f32x4 t = v;
+                v[0] = sh == 0 ? t[0] : sh == 1 ? t[1] : sh == 2 ? t[2] : t[3];
+                v[1] = sh == 0 ? t[1] : sh == 1 ? t[2] : t[3];
+                v[2] = sh == 0 ? t[2] : t[3];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = (xa + k < g.Hx) ? v[k] : 0.f;
-                }
-                if (!lok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (threadIdx.x + e * kBlock < npiece) {
-                    // the atom stride is only 8-byte aligned (== 2 mod 32 words): two 8-byte stores
-                    float2 *dst = reinterpret_cast<float2 *>(Hs + (line >> 2) * AST + (line & 3) * TW + col);
-                    dst[0] = float2{v[0], v[1]};
-                    dst[1] = float2{v[2], v[3]};
-                }
+                for (int k = 0; k < 4; ++k) v[k] = (xa + k < g.Hx) ? v[k] : 0.f;
+            }
+            if (!lok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (threadIdx.x + e * kBlock < npiece) {
+                // the atom stride is only 8-byte aligned (== 2 mod 32 words): two 8-byte stores
+                float2 *dst = reinterpret_cast<float2 *>(Hs + (line >> 2) * AST + (line & 3) * TW + col);
+                dst[0] = float2{v[0], v[1]};
+                dst[1] = float2{v[2], v[3]};
             }
         }
         // (V, R) windows of the channels of this column group: rows r0-(Ay-1) .. r0+RH-1, columns t0-(Ax-1) .. in pieces
@@ -712,7 +703,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
 //   atom chunk of MB atoms (zero beyond Hy/Hx/M), Wf for the chunk as [c][k = (m,b)][16 rows], b padded to 4.
 // ================================================================================================================
 constexpr int RC_RBK = 4;
-constexpr int RC_NE4 = 12;       // 16-byte staging pieces per thread: 128 lines * (HST/4 <= 24) / 256
+constexpr int RC_NE4_MAX = 12;   // 16-byte staging pieces per thread: 128 lines * (HST/4 <= 24) / 256
 
 template <int CB, int NB>
 __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, int xblocks, int cgroups, int ablate,
@@ -751,10 +742,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
     // clamped, always legal addresses (rows are only 4-byte aligned: unaligned dwordx4 is fine on gfx950); the raw
     // values of stage s+1 stay untouched in registers while stage s is multiplied and are masked (zero outside H /
     // beyond M) when commit() writes them to LDS with one ds_write_b128 each.
+    // Every thread handles exactly RC_NE4 pieces, unconditionally (pieces beyond the tile are clamped to piece 0 and not
+    // written): with conditional loads hipcc cannot count what is in flight and turns later waits into full drains.
+    constexpr int RC_NE4 = NB > 0 ? (128 * (16 + NB) + kBlock - 1) / kBlock : RC_NE4_MAX;
     const int q4 = HST >> 2;                          // pieces per line
     const int nlines = MB * RC_RBK;
     const int npiece = nlines * q4;
-    const int ne = (npiece + kBlock - 1) / kBlock;    // <= RC_NE4, wave-uniform
     const bool edge = x0 + HST > g.Hx;                // this workgroup's window crosses the right border
     const float *Hn = H + (size_t)n * g.M * g.Hy * g.Hx;
     int plc[RC_NE4];                                  // line << 8 | piece column, fixed over the sweep
@@ -774,15 +767,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
         if (nat > MB) nat = MB;
 #pragma unroll
         for (int e = 0; e < RC_NE4; ++e) {
-            if (e < ne) {
-                const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
-                int ml = line >> 2, r = rb0 + (line & 3);
-                ml = ml < nat ? ml : nat - 1;
-                r = r < g.Hy ? r : g.Hy - 1;
-                int xs = x0 + col;
-                xs = xs < g.Hx - 4 ? xs : g.Hx - 4;   // keep the 4 columns inside the row
-                pm[e] = *reinterpret_cast<const f32x4_u *>(Hn + ((size_t)(m0 + ml) * g.Hy + r) * g.Hx + xs);
-            }
+            const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
+            int ml = line >> 2, r = rb0 + (line & 3);
+            ml = ml < nat ? ml : nat - 1;
+            r = r < g.Hy ? r : g.Hy - 1;
+            int xs = x0 + col;
+            xs = xs < g.Hx - 4 ? xs : g.Hx - 4;   // keep the 4 columns inside the row
+            pm[e] = *reinterpret_cast<const f32x4_u *>(Hn + ((size_t)(m0 + ml) * g.Hy + r) * g.Hx + xs);
         }
     };
     auto commit = [&](int stage) {
@@ -791,24 +782,22 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
         if (nat > MB) nat = MB;
 #pragma unroll
         for (int e = 0; e < RC_NE4; ++e) {
-            if (e < ne) {
-                const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
-                const bool lok = (line >> 2) < nat && rb0 + (line & 3) < g.Hy;
-                f32x4 v = pm[e];
-                if (edge) {
-                    // the load started at min(x, Hx-4): shift the components back and zero the columns beyond the row
-                    const int xa = x0 + col;
-                    const int sh = xa - (xa < g.Hx - 4 ? xa : g.Hx - 4);
-                    const f32x4 t = v;
-                    v[0] = sh == 0 ? t[0] : sh == 1 ? t[1] : sh == 2 ? t[2] : t[3];
-                    v[1] = sh == 0 ? t[1] : sh == 1 ? t[2] : t[3];
-                    v[2] = sh == 0 ? t[2] : t[3];
+            const int line = plc[e] >> 8, col = (plc[e] & 255) << 2;
+            const bool lok = (line >> 2) < nat && rb0 + (line & 3) < g.Hy;
+            f32x4 v = pm[e];
+            if (edge) {
+                // the load started at min(x, Hx-4): shift the components back and zero the columns beyond the row
+                const int xa = x0 + col;
+                const int sh = xa - (xa < g.Hx - 4 ? xa : g.Hx - 4);
+                const f32x4 t = v;
+                v[0] = sh == 0 ? t[0] : sh == 1 ? t[1] : sh == 2 ? t[2] : t[3];
+                v[1] = sh == 0 ? t[1] : sh == 1 ? t[2] : t[3];
+                v[2] = sh == 0 ? t[2] : t[3];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = (xa + k < g.Hx) ? v[k] : 0.f;
-                }
-                if (!lok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (threadIdx.x + e * kBlock < npiece) *reinterpret_cast<f32x4 *>(Hs + line * HST + col) = v;
+                for (int k = 0; k < 4; ++k) v[k] = (xa + k < g.Hx) ? v[k] : 0.f;
             }
+            if (!lok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (threadIdx.x + e * kBlock < npiece) *reinterpret_cast<f32x4 *>(Hs + line * HST + col) = v;
         }
     };
 
@@ -821,13 +810,46 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
     if (!(ablate & 1)) prefetch(0);
     int stage = 0;
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = dbg ? stamp() : 0ull;
+    f32x4 acc[RC_RBK][CB];
+    // col2im along the row axis for the rows rb0 .. rb0+RC_RBK-1 held in acc, rows in order.  The ring is private to the
+    // wave and LDS operations of one wave execute in program order, so the accumulate (ds_add_f32, no return) needs no
+    // wait before the read of the finished row; only the compiler has to be kept from reordering them.
+    auto col2im = [&](int rb0) {
+#pragma unroll
+        for (int rr = 0; rr < RC_RBK; ++rr) {
+            const int r = rb0 + rr;
+            const int y = r - 3 - 4 * kq;
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const f32x4 d = acc[rr][c];
+                const float emit = w2[c] + d[3];
+                w2[c] = w1[c] + d[2];
+                w1[c] = w0[c] + d[1];
+                w0[c] = d[0];
+                if (kq <= gmax) {
+                    float *rp = ring + ((wave * CB + c) * 16 + ((y + 64) & 15)) * 16 + j;
+                    __hip_atomic_fetch_add(rp, emit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+            asm volatile("" ::: "memory");
+            const int yd = r - 3 - 4 * gmax;
+            const int cc = lane >> 4;
+            if (cc < CB) {
+                float *rp = ring + ((wave * CB + cc) * 16 + ((yd + 64) & 15)) * 16 + j;
+                const float val = __hip_atomic_exchange(rp, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const int x = x0 + wave * 16 + j;
+                if (yd >= 0 && yd < g.Dy && x < g.Dx && c0 + cc < g.C)
+                    R[(((size_t)n * g.C + c0 + cc) * g.Dy + yd) * g.Dx + x] = val;
+            }
+            asm volatile("" ::: "memory");
+        }
+    };
+    // The col2im of a row block (it ends in conditional R stores) is deferred until the NEXT block's tile has been
+    // committed: hipcc cannot count conditional stores, so a vmcnt wait that follows them is a full drain, and the wait
+    // for the prefetched tile in commit() would otherwise also wait for R stores issued moments before (measured: 21 %
+    // of the kernel).  Deferred, nothing younger than the prefetch is outstanding when commit() waits.
+    int pending = -1;
     for (int rb0 = 0; rb0 < rows_total; rb0 += RC_RBK) {
-        f32x4 acc[RC_RBK][CB];
-#pragma unroll
-        for (int rr = 0; rr < RC_RBK; ++rr)
-#pragma unroll
-            for (int c = 0; c < CB; ++c) acc[rr][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
         for (int ch = 0; ch < nchunks; ++ch, ++stage) {
             const int m0 = ch * MB;
             STAMP(0);        // rest of the loop body (accumulator init, ...)
@@ -848,6 +870,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
             STAMP(2);        // W staging (first stage) + commit
             lds_barrier();
             STAMP(3);        // barrier 2
+            if (ch == 0) {
+                if (pending >= 0 && !(ablate & 2)) col2im(pending);
+#pragma unroll
+                for (int rr = 0; rr < RC_RBK; ++rr)
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) acc[rr][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            STAMP(6);        // deferred col2im + R stores of the previous row block
             if (stage + 1 < nstages && !(ablate & 1)) prefetch(stage + 1);   // in flight under the MFMAs below
             STAMP(4);        // prefetch issue
 
@@ -948,40 +978,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
         }
 
         STAMP(5);   // MFMA loop(s)
-        // col2im along the row axis, rows of this block in order.  The ring is private to the wave and LDS operations
-        // of one wave execute in program order, so the accumulate (ds_add_f32, no return) needs no wait before the
-        // read of the finished row; only the compiler has to be kept from reordering them.
-        if (!(ablate & 2))
-#pragma unroll
-        for (int rr = 0; rr < RC_RBK; ++rr) {
-            const int r = rb0 + rr;
-            const int y = r - 3 - 4 * kq;
-#pragma unroll
-            for (int c = 0; c < CB; ++c) {
-                const f32x4 d = acc[rr][c];
-                const float emit = w2[c] + d[3];
-                w2[c] = w1[c] + d[2];
-                w1[c] = w0[c] + d[1];
-                w0[c] = d[0];
-                if (kq <= gmax) {
-                    float *rp = ring + ((wave * CB + c) * 16 + ((y + 64) & 15)) * 16 + j;
-                    __hip_atomic_fetch_add(rp, emit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-            }
-            asm volatile("" ::: "memory");
-            const int yd = r - 3 - 4 * gmax;
-            const int cc = lane >> 4;
-            if (cc < CB) {
-                float *rp = ring + ((wave * CB + cc) * 16 + ((yd + 64) & 15)) * 16 + j;
-                const float val = __hip_atomic_exchange(rp, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                const int x = x0 + wave * 16 + j;
-                if (yd >= 0 && yd < g.Dy && x < g.Dx && c0 + cc < g.C)
-                    R[(((size_t)n * g.C + c0 + cc) * g.Dy + yd) * g.Dx + x] = val;
-            }
-            asm volatile("" ::: "memory");
-        }
-        STAMP(6);   // col2im + R stores
+        pending = rb0;
     }
+    if (pending >= 0 && !(ablate & 2)) col2im(pending);
     if (dbg && lane == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 4 + wave) * 8 + k] = phase[k];
@@ -1166,12 +1165,23 @@ int mfma_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R,
             if (P < 1) P = 1;
             if (P > ntiles) P = ntiles;
             const dim3 grid((unsigned)P, MT);
-            if (fused)
-                hipLaunchKernelGGL((k_mfma_corr_W_persist<true>), grid, dim3(kBlock), lds_p, s, g, tiles_y, tiles_x,
-                                   ctx->ablate, V, R, W, H_inout, (float *)nullptr, (float *)nullptr, reg);
+            const int ne = (wpieces + kBlock - 1) / kBlock;   // 1..CP_XE4
+#define LAUNCH_CP(NE_)                                                                                              \
+    do {                                                                                                            \
+        if (fused)                                                                                                  \
+            hipLaunchKernelGGL((k_mfma_corr_W_persist<true, NE_>), grid, dim3(kBlock), lds_p, s, g, tiles_y, tiles_x, \
+                               ctx->ablate, V, R, W, H_inout, (float *)nullptr, (float *)nullptr, reg);            \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_mfma_corr_W_persist<false, NE_>), grid, dim3(kBlock), lds_p, s, g, tiles_y,        \
+                               tiles_x, ctx->ablate, V, R, W, (float *)nullptr, neg, pos, 0.f);                     \
+    } while (0)
+            if (ne <= 1)
+                LAUNCH_CP(1);
+            else if (ne == 2)
+                LAUNCH_CP(2);
             else
-                hipLaunchKernelGGL((k_mfma_corr_W_persist<false>), grid, dim3(kBlock), lds_p, s, g, tiles_y, tiles_x,
-                                   ctx->ablate, V, R, W, (float *)nullptr, neg, pos, 0.f);
+                LAUNCH_CP(3);
+#undef LAUNCH_CP
             TNMF_LAUNCH_CHECK();
             return TNMF_OK;
         }
