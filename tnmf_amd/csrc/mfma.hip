@@ -48,6 +48,14 @@ __device__ __forceinline__ unsigned long long stamp() {
             tprev = t_;                             \
         }                                           \
     } while (0)
+// XCD-aware workgroup numbering (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, so
+// ids b and b+8 share an L2.  The remap gives every XCD a contiguous chunk of the logical grid, so that logically
+// adjacent workgroups (neighbouring column blocks of one sample: shared halo, same DRAM pages) run on one XCD at about
+// the same time.  Bijective for any grid size (cdna_hip_programming.md, T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -718,7 +726,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
     float *Hs = Wl + CB * K4 * 16;             // [MB][RC_RBK][HST]
     float *ring = Hs + MB * RC_RBK * HST;      // [4 waves][CB][16 slots][16 cols]
 
-    unsigned bid = blockIdx.x;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int xb = bid % xblocks;
     bid /= xblocks;
     const int cg = bid % cgroups;
