@@ -107,7 +107,7 @@ def cpu_baseline(cfg, budget_s=20.0):
         return time.perf_counter() - t0
 
     t1 = run(1)
-    n = int(max(1, min(8, budget_s // max(t1, 1e-3))))
+    n = int(max(1, min(32, budget_s // max(t1, 1e-3))))   # ~budget_s seconds of host work
     t = run(n) if n > 1 else t1
     per_sample = t / n
     its = 1.0 / (per_sample * cfg['N'])
