@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
 // ================================================================================================================
 constexpr int CP_TY = 8, CP_RB = 2, CP_XE4 = 3;   // CP_XE4: 4-column window pieces prefetched per thread (39 x 16 / 256)
 
-template <bool FUSED, int NE>
+template <bool FUSED, int NE, int NBP>
 __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int tiles_y, int tiles_x, int ablate,
                                                                    const float *__restrict__ V,
                                                                    const float *__restrict__ Rr,
@@ -374,9 +374,54 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
             }
         }
 
-        // k loop over (a, b-pair) of channel c, two operand register sets (see k_mfma_corr_W)
         const float2 *xb = Xs + (wave * CP_RB) * CW_XSTR + j + h;
         const float *wb = Ws + c * KC * 32 + h * 32 + j;
+        if (NBP > 0) {
+            // k loop row by row of the atom, the NBP tap pairs of a row fully unrolled (Axp = 2*NBP at compile time: every
+            // LDS offset inside a row is an immediate; only one add per row and operand is left -- the loop is bound by
+            // instruction issue otherwise).  Two operand register sets, MFMAs and LDS reads alternated by the scheduler.
+            constexpr int NB1 = NBP > 0 ? NBP : 1;
+            float wA[NB1], wB[NB1];
+            float2 xA[NB1][CP_RB], xB[NB1][CP_RB];
+#define CPR_LOAD(w_, x_, A_)                                                                         \
+    do {                                                                                             \
+        const float *wr_ = wb + (A_) * (NBP * 64);                                                   \
+        const float2 *xr_ = xb + (A_) * CW_XSTR;                                                     \
+        _Pragma("unroll") for (int q = 0; q < NBP; ++q) {                                            \
+            w_[q] = wr_[q * 64];                                                                     \
+            _Pragma("unroll") for (int rb = 0; rb < CP_RB; ++rb) x_[q][rb] = xr_[rb * CW_XSTR + 2 * q]; \
+        }                                                                                            \
+    } while (0)
+#define CPR_MMA(w_, x_)                                                                              \
+    do {                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < NBP; ++q)                                              \
+            _Pragma("unroll") for (int rb = 0; rb < CP_RB; ++rb) {                                   \
+                an[rb] = mfma32(x_[q][rb].x, w_[q], an[rb]);                                         \
+                ap[rb] = mfma32(x_[q][rb].y, w_[q], ap[rb]);                                         \
+            }                                                                                        \
+    } while (0)
+            if (!(ablate & 4)) {
+                int a = 0;
+                CPR_LOAD(wA, xA, 0);
+                while (a + 2 <= g.Ay) {
+                    CPR_LOAD(wB, xB, a + 1);
+                    CPR_MMA(wA, xA);
+                    a += 2;
+                    const int an_ = a < g.Ay ? a : g.Ay - 1;   // last round: a redundant (legal) reload
+                    CPR_LOAD(wA, xA, an_);
+                    CPR_MMA(wB, xB);
+#pragma unroll
+                    for (int k = 0; k < 2 * NBP * (1 + CP_RB); ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMAs (V and R of one operand pair)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                    }
+                }
+                if (a < g.Ay) CPR_MMA(wA, xA);
+            }
+#undef CPR_LOAD
+#undef CPR_MMA
+        } else {
+        // k loop over (a, b-pair) of channel c, two operand register sets (see k_mfma_corr_W)
         const int nsteps = g.Ay * (Axp >> 1);
         int b2 = 0, xo = 0, k = (ablate & 4) ? nsteps : 0;
         float wA, wB;
@@ -418,6 +463,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
 #undef CP_LOAD
 #undef CP_NEXT
 #undef CP_MMA
+        }
 
         if (c == g.C - 1 && atom < g.M && !(ablate & (8 | 64))) {
 #pragma unroll
@@ -1174,21 +1220,32 @@ int mfma_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R,
             if (P > ntiles) P = ntiles;
             const dim3 grid((unsigned)P, MT);
             const int ne = (wpieces + kBlock - 1) / kBlock;   // 1..CP_XE4
-#define LAUNCH_CP(NE_)                                                                                              \
+#define LAUNCH_CP(NE_, NBP_)                                                                                        \
     do {                                                                                                            \
         if (fused)                                                                                                  \
-            hipLaunchKernelGGL((k_mfma_corr_W_persist<true, NE_>), grid, dim3(kBlock), lds_p, s, g, tiles_y, tiles_x, \
-                               ctx->ablate, V, R, W, H_inout, (float *)nullptr, (float *)nullptr, reg);            \
+            hipLaunchKernelGGL((k_mfma_corr_W_persist<true, NE_, NBP_>), grid, dim3(kBlock), lds_p, s, g, tiles_y,   \
+                               tiles_x, ctx->ablate, V, R, W, H_inout, (float *)nullptr, (float *)nullptr, reg);    \
         else                                                                                                        \
-            hipLaunchKernelGGL((k_mfma_corr_W_persist<false, NE_>), grid, dim3(kBlock), lds_p, s, g, tiles_y,        \
+            hipLaunchKernelGGL((k_mfma_corr_W_persist<false, NE_, NBP_>), grid, dim3(kBlock), lds_p, s, g, tiles_y,  \
                                tiles_x, ctx->ablate, V, R, W, (float *)nullptr, neg, pos, 0.f);                     \
     } while (0)
-            if (ne <= 1)
-                LAUNCH_CP(1);
+            const int nbp = Axp >> 1;   // tap pairs per atom row; unrolled kernels for the common atom widths
+            if (ne <= 1 && nbp == 3)
+                LAUNCH_CP(1, 3);
+            else if (ne <= 1 && nbp == 4)
+                LAUNCH_CP(1, 4);
+            else if (ne <= 1 && nbp == 5)
+                LAUNCH_CP(1, 5);
+            else if (ne <= 1 && nbp == 6)
+                LAUNCH_CP(1, 6);
+            else if (ne <= 2 && nbp == 8)
+                LAUNCH_CP(2, 8);
+            else if (ne <= 1)
+                LAUNCH_CP(1, 0);
             else if (ne == 2)
-                LAUNCH_CP(2);
+                LAUNCH_CP(2, 0);
             else
-                LAUNCH_CP(3);
+                LAUNCH_CP(3, 0);
 #undef LAUNCH_CP
             TNMF_LAUNCH_CHECK();
             return TNMF_OK;
