@@ -99,6 +99,19 @@ int tnmf_hip_convolve_multi_1d(tnmf_hip_ctx *ctx, int dtype, int ndim, size_t ro
                                const void *in, void *out, void *tmp, const double *kernel0, int len0,
                                const double *kernel1, int len1, void *stream);
 
+/* ---- reconstruction modes other than 'valid' --------------------------------------------------------------------
+ * Every mode of the reference is a 'valid' reconstruction of padded activations (padding table:
+ * tnmf/backends/_PyTorchBackend.py:42-52, applied in tnmf/backends/PyTorch.py:36-43): 'full' pads A-1 zeros on both
+ * sides, 'circular' / 'reflect' pad A-1 wrapped / mirrored elements on the left.  The activation tensor of mode `mode`
+ * has shift shape S = D-A+1 ('full') or D ('circular', 'reflect'); the padded one always has D+A-1, which is what all
+ * the primitives above take.  The H gradient of a mode is the 'valid' gradient folded back by the adjoint of the pad. */
+enum { TNMF_MODE_VALID = 0, TNMF_MODE_FULL = 1, TNMF_MODE_CIRCULAR = 2, TNMF_MODE_REFLECT = 3 };
+
+/* Hpad[N,M,*(D+A-1)] = pad(H[N,M,*S]) */
+int tnmf_hip_pad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *H, void *Hpad, void *stream);
+/* G[N,M,*S] = pad^T(Gpad[N,M,*(D+A-1)]): every padded position's gradient is summed into the activation it copies */
+int tnmf_hip_fold_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *Gpad, void *G, void *stream);
+
 /* ---- fused half steps: performance path (same math as the primitives + mu_update) --------------------------- */
 
 /* TransformInvariantNMF._update_H without inhibition (TransformInvariantNMF.py:246-250,271):

@@ -126,7 +126,7 @@ def normalize(arr: np.ndarray, axes) -> None:
 
 
 def init_matrices(V: np.ndarray, atom_shape: Sequence[int], n_atoms: int,
-                  W: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+                  W: Optional[np.ndarray] = None, mode: str = 'valid') -> Tuple[np.ndarray, np.ndarray]:
     """
     Random initialisation from the *global legacy* NumPy RNG: H is drawn first, then W (if not kept),
     both as ``1 - rand`` in float64 and cast to ``V.dtype``; W is normalised over the atom axes.
@@ -134,12 +134,65 @@ def init_matrices(V: np.ndarray, atom_shape: Sequence[int], n_atoms: int,
     """
     atom_shape = tuple(atom_shape)
     k = len(atom_shape)
-    shifts = transform_shape(V.shape[2:], atom_shape)
+    shifts = transform_shape(V.shape[2:], atom_shape, mode)
     H = np.asarray(1 - np.random.rand(V.shape[0], n_atoms, *shifts), dtype=V.dtype)
     if W is None:
         W = np.asarray(1 - np.random.rand(n_atoms, V.shape[1], *atom_shape), dtype=V.dtype)
         normalize(W, tuple(range(-k, 0)))
     return W, H
+
+
+# ----------------------------------------------------------------------------------------------------------
+# reconstruction modes other than 'valid': every mode is a 'valid' reconstruction of padded activations
+# (backends/_PyTorchBackend.py:42-52 padding table, backends/PyTorch.py:36-41), so its gradients are the 'valid'
+# gradients followed by the adjoint of the padding ("fold").
+# ----------------------------------------------------------------------------------------------------------
+MODES = ('valid', 'full', 'circular', 'reflect')
+
+
+def pad_activations(H: np.ndarray, atom_shape: Sequence[int], mode: str) -> np.ndarray:
+    """H[n,m,*D'] -> Hpad[n,m,*(D+A-1)]: zeros on both sides ('full'), wrap / reflect on the left ('circular'/'reflect')."""
+    lead = ((0, 0), (0, 0))
+    if mode == 'valid':
+        return H
+    if mode == 'full':
+        return np.pad(H, lead + tuple((a - 1, a - 1) for a in atom_shape))
+    if mode == 'circular':
+        return np.pad(H, lead + tuple((a - 1, 0) for a in atom_shape), mode='wrap')
+    if mode == 'reflect':
+        return np.pad(H, lead + tuple((a - 1, 0) for a in atom_shape), mode='reflect')
+    raise ValueError(mode)
+
+
+def pad_source_index(n_shift: int, a: int, mode: str) -> np.ndarray:
+    """For one shift axis: index into H of every padded position (-1 = a zero)."""
+    if mode == 'valid':
+        return np.arange(n_shift)
+    if mode == 'full':
+        return np.concatenate([np.full(a - 1, -1), np.arange(n_shift), np.full(a - 1, -1)])
+    if mode == 'circular':
+        return np.concatenate([np.arange(n_shift - (a - 1), n_shift), np.arange(n_shift)])
+    if mode == 'reflect':
+        return np.concatenate([np.arange(a - 1, 0, -1), np.arange(n_shift)])
+    raise ValueError(mode)
+
+
+def fold_gradient(Gpad: np.ndarray, shift_shape: Sequence[int], atom_shape: Sequence[int], mode: str) -> np.ndarray:
+    """Adjoint of pad_activations: sums the gradient of every padded position into the activation it copies."""
+    if mode == 'valid':
+        return Gpad
+    G = Gpad
+    k = len(atom_shape)
+    for ax in range(k):
+        axis = G.ndim - k + ax
+        src = pad_source_index(shift_shape[ax], atom_shape[ax], mode)
+        out = np.zeros(G.shape[:axis] + (shift_shape[ax],) + G.shape[axis + 1:], dtype=G.dtype)
+        Gm, om = np.moveaxis(G, axis, 0), np.moveaxis(out, axis, 0)
+        for jpos, u in enumerate(src):
+            if u >= 0:
+                om[u] += Gm[jpos]
+        G = out
+    return G
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -154,12 +207,15 @@ def contract(x, x_idx, y, y_idx, out_idx):
     return np.einsum(x, x_idx, y, y_idx, out_idx, optimize=True)
 
 
-def reconstruct(W: np.ndarray, H: np.ndarray, impl: str = 'contract') -> np.ndarray:
+def reconstruct(W: np.ndarray, H: np.ndarray, impl: str = 'contract', mode: str = 'valid') -> np.ndarray:
     """
     R[n,c,d] = sum_m sum_a H[n,m,d+a] * W[m,c,A-1-a]   ('valid' part of the full convolution H (*) W).
     backends/NumPy.py:122-132 (windows :124-127, flipped W :130).
     ``impl``: 'contract' (windows + one contraction, the reference's algorithm), 'shiftsum' or 'c'.
+    ``mode``: reconstruction mode; non-'valid' modes pad H first (backends/PyTorch.py:36-43).
     """
+    if mode != 'valid':
+        return reconstruct(W, pad_activations(H, W.shape[2:], mode), impl)
     if impl == 'c':
         return _c_reconstruct(W, H)
     if impl == 'shiftsum':
@@ -193,14 +249,17 @@ def _correlate_with_W(W: np.ndarray, X: np.ndarray, impl: str = 'contract') -> n
     return contract(W, [m_, c_] + a_, Xw, [n_, c_] + d_ + a_, [n_, m_] + d_)
 
 
-def gradient_H(V: np.ndarray, W: np.ndarray, H: np.ndarray, s: slice = slice(None), impl: str = 'contract'):
+def gradient_H(V: np.ndarray, W: np.ndarray, H: np.ndarray, s: slice = slice(None), impl: str = 'contract',
+               mode: str = 'valid'):
     """
     neg = correlation of V[s] with W, pos = correlation of R = reconstruct(W, H[s]) with W; both of H[s]'s shape.
-    backends/NumPy.py:93-120.
+    backends/NumPy.py:93-120.  Other modes: the same on the padded activations, folded back (what autograd does in
+    backends/_PyTorchBackend.py:91-110).
     """
+    A = W.shape[2:]
     neg = _correlate_with_W(W, V[s], impl)
-    pos = _correlate_with_W(W, reconstruct(W, H[s], impl), impl)
-    return neg, pos
+    pos = _correlate_with_W(W, reconstruct(W, H[s], impl, mode), impl)
+    return fold_gradient(neg, H.shape[2:], A, mode), fold_gradient(pos, H.shape[2:], A, mode)
 
 
 def _correlate_H_with(X: np.ndarray, H: np.ndarray, A: Sequence[int], impl: str = 'contract') -> np.ndarray:
@@ -222,23 +281,25 @@ def _correlate_H_with(X: np.ndarray, H: np.ndarray, A: Sequence[int], impl: str 
     return np.flip(G, _shift_axes(k))
 
 
-def gradient_W(V: np.ndarray, W: np.ndarray, H: np.ndarray, s: slice = slice(None), impl: str = 'contract'):
+def gradient_W(V: np.ndarray, W: np.ndarray, H: np.ndarray, s: slice = slice(None), impl: str = 'contract',
+               mode: str = 'valid'):
     """neg from V[s], pos from R = reconstruct(W, H[s]); both of W's shape.  backends/NumPy.py:69-91."""
     A = W.shape[2:]
-    Hs = H[s]
+    Hs = pad_activations(H[s], A, mode)
     neg = _correlate_H_with(V[s], Hs, A, impl)
     pos = _correlate_H_with(reconstruct(W, Hs, impl), Hs, A, impl)
     return neg, pos
 
 
-def partial_reconstruct(W: np.ndarray, H: np.ndarray, i_atom: int, impl: str = 'contract') -> np.ndarray:
+def partial_reconstruct(W: np.ndarray, H: np.ndarray, i_atom: int, impl: str = 'contract',
+                        mode: str = 'valid') -> np.ndarray:
     """backends/_Backend.py:124-125."""
-    return reconstruct(W[i_atom:i_atom + 1], H[:, i_atom:i_atom + 1], impl)
+    return reconstruct(W[i_atom:i_atom + 1], H[:, i_atom:i_atom + 1], impl, mode)
 
 
-def energy(V: np.ndarray, W: np.ndarray, H: np.ndarray, impl: str = 'contract') -> float:
+def energy(V: np.ndarray, W: np.ndarray, H: np.ndarray, impl: str = 'contract', mode: str = 'valid') -> float:
     """E = 1/2 sum (V - R)^2.  backends/_Backend.py:127-130."""
-    R = reconstruct(W, H, impl)
+    R = reconstruct(W, H, impl, mode)
     assert R.shape == V.shape
     return float(0.5 * np.sum(np.square(V - R)))
 
@@ -359,8 +420,10 @@ class OracleNMF:
     TransformInvariantNMF.py:142-186 (ctor), :282-348 (fit_batch), :350-442 (fit_minibatches), :506-531.
     """
 
-    def __init__(self, n_atoms: int, atom_shape: Sequence[int], inhibition_range=None, impl: str = 'contract'):
+    def __init__(self, n_atoms: int, atom_shape: Sequence[int], inhibition_range=None, impl: str = 'contract',
+                 reconstruction_mode: str = 'valid'):
         self.impl = impl
+        self.mode = reconstruction_mode
         self.n_atoms = n_atoms
         self.atom_shape = tuple(atom_shape)
         k = len(self.atom_shape)
@@ -379,18 +442,18 @@ class OracleNMF:
     # -- properties mirroring the reference's read-outs (TransformInvariantNMF.py:188-215) --
     @property
     def R(self):
-        return reconstruct(self.W, self.H, self.impl)
+        return reconstruct(self.W, self.H, self.impl, self.mode)
 
     def R_partial(self, i_atom: int):
-        return partial_reconstruct(self.W, self.H, i_atom, self.impl)
+        return partial_reconstruct(self.W, self.H, i_atom, self.impl, self.mode)
 
     def energy(self) -> float:
-        return energy(self.V, self.W, self.H, self.impl)
+        return energy(self.V, self.W, self.H, self.impl, self.mode)
 
     # -- half steps --
     def update_H(self, s=slice(None), sparsity=0., inhibition=0., cross_inhibition=0.):
         """TransformInvariantNMF.py:246-271."""
-        neg, pos = gradient_H(self.V, self.W, self.H, s, self.impl)
+        neg, pos = gradient_H(self.V, self.W, self.H, s, self.impl, self.mode)
         if inhibition > 0 or cross_inhibition > 0:
             k = len(self.atom_shape)
             g = convolve_multi_1d(self.H[s], self._kernels, range(-k, 0))
@@ -402,12 +465,12 @@ class OracleNMF:
 
     def update_W(self, s=slice(None)):
         """TransformInvariantNMF.py:240-244."""
-        neg, pos = gradient_W(self.V, self.W, self.H, s, self.impl)
+        neg, pos = gradient_W(self.V, self.W, self.H, s, self.impl, self.mode)
         multiplicative_update(self.W, neg, pos, self.eps, normalization_axes=self._norm_axes)
 
     def _accumulate(self, acc_neg, acc_pos, lam, s):
         """TransformInvariantNMF.py:444-455 (the += / *= forms, including their in-place side effects)."""
-        neg, pos = gradient_W(self.V, self.W, self.H, s, self.impl)
+        neg, pos = gradient_W(self.V, self.W, self.H, s, self.impl, self.mode)
         if lam == 1:
             acc_neg = acc_neg + neg if np.isscalar(acc_neg) else acc_neg.__iadd__(neg)
             acc_pos = acc_pos + pos if np.isscalar(acc_pos) else acc_pos.__iadd__(pos)
@@ -423,7 +486,7 @@ class OracleNMF:
 
     def _init(self, V, keep_W):
         self.V = V
-        self.W, self.H = init_matrices(V, self.atom_shape, self.n_atoms, self.W if keep_W else None)
+        self.W, self.H = init_matrices(V, self.atom_shape, self.n_atoms, self.W if keep_W else None, self.mode)
 
     # -- full batch --
     def fit_batch(self, V, n_iterations=1000, update_H=True, update_W=True, keep_W=False, sparsity_H=0.,

@@ -40,8 +40,8 @@ def test_no_cpu_fallback():
     from tnmf_amd.backends.HIP import HIP_Backend
     with pytest.raises(RuntimeError):
         HIP_Backend()
-    with pytest.raises(NotImplementedError):
-        HIP_Backend(reconstruction_mode='circular')
+    with pytest.raises(ValueError):
+        HIP_Backend(reconstruction_mode='same')          # unknown mode: ValueError like _PyTorchBackend.py:50-52
 
 
 def test_product_never_imports_oracle():

@@ -261,9 +261,55 @@ def test_matrix_core_kernels_at_baseline_sizes(C, D, M, A):
         assert relmax(got, want) < 2e-5
 
 
+MODE_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'modes_*.npz')))
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-10), (np.float32, 2e-5)], ids=['f64', 'f32'])
+@pytest.mark.parametrize('case', MODE_CASES, ids=[os.path.basename(p)[6:-4] for p in MODE_CASES])
+def test_mode_primitives_against_reference_golden(case, dtype, tol):
+    """'full' / 'circular' / 'reflect': pad + 'valid' kernels + fold against the reference PyTorch backend's outputs."""
+    g = np.load(case)
+    mode = os.path.basename(case).split('_')[1]
+    V, s = g['V'].astype(dtype), _slice(g)
+    A, M = g['W'].shape[2:], g['W'].shape[0]
+    be = HIP_Backend(reconstruction_mode=mode)
+    np.random.seed(1)
+    _, H0 = be.initialize(V, tuple(A), M, None, tuple(range(-len(A), 0)))
+    assert tuple(H0.shape) == tuple(g['init_H_shape'])
+    W, H = dev(g['W'], dtype), dev(g['H'], dtype)
+    assert relmax(be.to_ndarray(be.reconstruct(W, H)), g['R']) < tol
+    neg, pos = be.reconstruction_gradient_H(V, W, H, s)
+    assert neg.shape == H[s].shape
+    assert relmax(be.to_ndarray(neg), g['neg_H']) < tol and relmax(be.to_ndarray(pos), g['pos_H']) < tol
+    neg, pos = be.reconstruction_gradient_W(V, W, H, s)
+    assert relmax(be.to_ndarray(neg), g['neg_W']) < tol and relmax(be.to_ndarray(pos), g['pos_W']) < tol
+    assert abs(be.reconstruction_energy(V, W, H) - float(g['energy'])) / float(g['energy']) < tol
+
+
+@pytest.mark.parametrize('mode,E', [('full', 1.87180), ('circular', 3.13228), ('reflect', 3.16430)])
+def test_known_answer_1d_modes_f64(mode, E):
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=3, atom_shape=(5,), backend='hip', reconstruction_mode=mode)
+    nmf.fit(V_1D, inhibition_strength=0.1, n_iterations=10)
+    assert np.isclose(nmf._energy_function(), E)                  # tnmf/tests/test_1d.py:17-22
+
+
+@pytest.mark.parametrize('mode,E', [('full', 345.82498), ('circular', 265.35091)])
+def test_known_answer_2d_rgb_modes_f64(mode, E):
+    V = racoon_rgb_V()
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=10, atom_shape=(7, 7), backend='hip', reconstruction_mode=mode)
+    nmf.fit(V, sparsity_H=0.1, n_iterations=10)
+    assert np.isclose(nmf._energy_function(), E)                  # tnmf/tests/test_backends.py:17-22
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7), impl='c', reconstruction_mode=mode)
+    ref.fit(V, sparsity_H=0.1, n_iterations=10)
+    assert np.allclose(nmf.W, ref.W) and np.allclose(nmf.H, ref.H) and np.allclose(nmf.R, ref.R)
+
+
 def test_errors_like_the_reference():
-    with pytest.raises(NotImplementedError):
-        HIP_Backend(reconstruction_mode='full')                   # NumPy.py:26-27 precedent
+    with pytest.raises(ValueError):
+        HIP_Backend(reconstruction_mode='same')                   # unknown mode (_PyTorchBackend.py:50-52)
     be = HIP_Backend()
     with pytest.raises(TypeError):
         be.initialize(np.ones((1, 1, 8), dtype=np.int32), (3,), 2, None, (-1,))

@@ -166,3 +166,46 @@ def test_known_answer_stream_limited():
     nmf.fit(V, sparsity_H=0.1, algorithm=orc.MiniBatchAlgorithm.Cyclic_MU, subsample_size=50, max_subsamples=5,
             batch_size=3, n_epochs=5, sag_lambda=0.8)
     assert np.isclose(nmf.energy(), 629.109136)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# reconstruction modes 'full', 'circular', 'reflect' 
+# ---------------------------------------------------------------------------------------------------------
+MODE_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'modes_*.npz')))
+
+
+@pytest.mark.parametrize('path', MODE_CASES, ids=[os.path.basename(p)[6:-4] for p in MODE_CASES])
+def test_mode_primitives_match_reference_backend(path):
+    """Golden vectors of the genuine reference PyTorch backend in the non-'valid' modes (tools/make_golden.py)."""
+    g = np.load(path)
+    mode = os.path.basename(path).split('_')[1]
+    V, W, H, s = g['V'], g['W'], g['H'], _slice(g)
+    assert H.shape[2:] == orc.transform_shape(V.shape[2:], W.shape[2:], mode)
+    tol = dict(rtol=1e-12, atol=1e-12)
+    for impl in ('contract', 'c'):
+        np.testing.assert_allclose(orc.reconstruct(W, H, impl, mode), g['R'], **tol)
+        neg, pos = orc.gradient_H(V, W, H, s, impl, mode)
+        np.testing.assert_allclose(neg, g['neg_H'], **tol)
+        np.testing.assert_allclose(pos, g['pos_H'], **tol)
+        neg, pos = orc.gradient_W(V, W, H, s, impl, mode)
+        np.testing.assert_allclose(neg, g['neg_W'], **tol)
+        np.testing.assert_allclose(pos, g['pos_W'], **tol)
+        assert np.isclose(orc.energy(V, W, H, impl, mode), float(g['energy']), rtol=1e-13)
+
+
+@pytest.mark.parametrize('mode,E', [('full', 1.87180), ('circular', 3.13228), ('reflect', 3.16430)])
+def test_known_answer_1d_modes(mode, E):
+    """tnmf/tests/test_1d.py:17-22 (the reference keeps the 'reflect' value but does not run it, :27)."""
+    np.random.seed(42)
+    nmf = orc.OracleNMF(n_atoms=3, atom_shape=(5,), reconstruction_mode=mode)
+    nmf.fit(V_1D, inhibition_strength=0.1, n_iterations=10)
+    assert np.isclose(nmf.energy(), E)
+
+
+@pytest.mark.parametrize('mode,E', [('full', 345.82498), ('circular', 265.35091)])
+def test_known_answer_2d_rgb_modes(mode, E):
+    """tnmf/tests/test_backends.py:17-22."""
+    np.random.seed(42)
+    nmf = orc.OracleNMF(n_atoms=10, atom_shape=(7, 7), impl='c', reconstruction_mode=mode)
+    nmf.fit(racoon_rgb_V(), sparsity_H=0.1, n_iterations=10)
+    assert np.isclose(nmf.energy(), E)

@@ -19,7 +19,10 @@ EXPORTS = (
     'tnmf_hip_ctx_reserve', 'tnmf_hip_ctx_set_path', 'tnmf_hip_ctx_last_path', 'tnmf_hip_reconstruct',
     'tnmf_hip_grad_H', 'tnmf_hip_grad_W', 'tnmf_hip_mu_update', 'tnmf_hip_normalize_W', 'tnmf_hip_energy',
     'tnmf_hip_convolve_multi_1d', 'tnmf_hip_update_H', 'tnmf_hip_grad_W_fused', 'tnmf_hip_apply_W',
+    'tnmf_hip_pad_H', 'tnmf_hip_fold_H',
 )
+
+MODES = {'valid': 0, 'full': 1, 'circular': 2, 'reflect': 3}
 
 PATHS = {'auto': 0, 'generic': 1, 'mfma': 2}
 
@@ -74,6 +77,8 @@ def load() -> ctypes.CDLL:
     lib.tnmf_hip_update_H.argtypes = [vp, gp, vp, vp, vp, vp, ci, cd, cd, vp]
     lib.tnmf_hip_grad_W_fused.argtypes = [vp, gp, vp, vp, vp, vp, ci, vp, vp]
     lib.tnmf_hip_apply_W.argtypes = [vp, gp, vp, vp, cd, vp]
+    lib.tnmf_hip_pad_H.argtypes = [vp, gp, ci, vp, vp, vp]
+    lib.tnmf_hip_fold_H.argtypes = [vp, gp, ci, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int or name not in ('tnmf_hip_strerror', 'tnmf_hip_ctx_last_path'):

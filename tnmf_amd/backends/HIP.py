@@ -51,7 +51,9 @@ class HIP_Backend(Backend):
 
     Parameters
     ----------
-    reconstruction_mode : only ``'valid'`` (like the reference NumPy backend, NumPy.py:26-27)
+    reconstruction_mode : ``'valid'`` (the fused matrix-core path), or ``'full'`` / ``'circular'`` / ``'reflect'``: these
+           pad the activations (tnmf_hip_pad_H), run the same 'valid' kernels on the padded tensor and fold the H gradient
+           back (tnmf_hip_fold_H) -- the padding table of the reference's _PyTorchBackend.py:42-52
     device : CUDA/HIP device index or ``torch.device``; default: the current device
     path : ``'auto'`` | ``'generic'`` | ``'mfma'`` -- kernel family (``'auto'`` = MFMA where the shape allows)
     init : ``'reference'`` draws H then W from the global legacy NumPy RNG exactly like the reference
@@ -63,9 +65,11 @@ class HIP_Backend(Backend):
 
     def __init__(self, reconstruction_mode: str = 'valid', device=None, path: str = 'auto', init: str = 'reference',
                  process_group=None):
-        if reconstruction_mode != 'valid':
-            raise NotImplementedError('The hip backend only supports the "valid" reconstruction mode.')
+        if reconstruction_mode not in _lib.MODES:
+            raise ValueError(f'Unsupported reconstruction mode "{reconstruction_mode}". '
+                             f'Please choose "valid", "full", "circular", or "reflect".')
         super().__init__(reconstruction_mode=reconstruction_mode)
+        self._mode = _lib.MODES[reconstruction_mode]
         self._lib = _lib.load()  # raises when the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError('The hip backend needs a GPU (torch.cuda.is_available() is False); there is no CPU path.')
@@ -167,6 +171,31 @@ class HIP_Backend(Backend):
         """
         return sharding.local_minibatches(self.n_samples, self._rank, self._world, batch_size)
 
+    @property
+    def _padded_shape(self) -> Tuple[int, ...]:
+        return tuple(d + a - 1 for d, a in zip(self._sample_shape, self.atom_shape))
+
+    def _pad(self, H: torch.Tensor) -> torch.Tensor:
+        """Activations of this mode -> the padded tensor every kernel works on (identity for 'valid')."""
+        if self._mode == 0:
+            return H
+        assert H.is_contiguous() and tuple(H.shape[2:]) == self._transform_shape
+        Hp = torch.empty(tuple(H.shape[:2]) + self._padded_shape, dtype=H.dtype, device=H.device)
+        g = self._geom(H.shape[0], H.shape[1])
+        _lib.check(self._lib.tnmf_hip_pad_H(self._ctx, ctypes.byref(g), self._mode, _ptr(H), _ptr(Hp), self._stream()),
+                   'tnmf_hip_pad_H')
+        return Hp
+
+    def _fold(self, Gp: torch.Tensor) -> torch.Tensor:
+        """Gradient w.r.t. the padded activations -> gradient w.r.t. the activations (adjoint of _pad)."""
+        if self._mode == 0:
+            return Gp
+        G = torch.empty(tuple(Gp.shape[:2]) + self._transform_shape, dtype=Gp.dtype, device=Gp.device)
+        g = self._geom(Gp.shape[0], Gp.shape[1])
+        _lib.check(self._lib.tnmf_hip_fold_H(self._ctx, ctypes.byref(g), self._mode, _ptr(Gp), _ptr(G), self._stream()),
+                   'tnmf_hip_fold_H')
+        return G
+
     def _all_reduce(self, t: torch.Tensor) -> None:
         sharding.all_reduce_sum(t, self._group)
 
@@ -211,6 +240,7 @@ class HIP_Backend(Backend):
         if not H.is_contiguous():
             H = H.contiguous()
         self._check_H(H, W.shape[0])
+        H = self._pad(H)
         R = torch.empty((H.shape[0], self.n_channels) + self._sample_shape, dtype=self._torch_dtype, device=self._device)
         g = self._geom(H.shape[0], W.shape[0])
         _lib.check(self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(H), _ptr(R),
@@ -224,17 +254,19 @@ class HIP_Backend(Backend):
         ls = self._local(s)
         Hs, Vs = H[ls], self._V_dev[ls]
         self._check_H(Hs, W.shape[0])
+        Hs = self._pad(Hs)
         neg, pos = torch.empty_like(Hs), torch.empty_like(Hs)
         g = self._geom(Hs.shape[0], W.shape[0])
         _lib.check(self._lib.tnmf_hip_grad_H(self._ctx, ctypes.byref(g), _ptr(Vs), None, _ptr(W), _ptr(Hs),
                                              _ptr(neg), _ptr(pos), self._stream()), 'tnmf_hip_grad_H')
-        return neg, pos
+        return self._fold(neg), self._fold(pos)
 
     def _local_grad_W(self, W, H, s) -> torch.Tensor:
         ls = self._local(s)
         Hs, Vs = H[ls], self._V_dev[ls]
         self._check_W(W)
         self._check_H(Hs, W.shape[0])
+        Hs = self._pad(Hs)
         negpos = torch.empty_like(self._negpos)
         g = self._geom(Hs.shape[0], W.shape[0])
         Rs = self._R_scratch[ls] if Hs.shape[0] else None
@@ -261,6 +293,7 @@ class HIP_Backend(Backend):
         """1/2 sum (V - R)^2 (reference: _Backend.py:127-130) -> tnmf_hip_energy (+ all-reduce)."""
         self._check_W(W)
         self._check_H(H, W.shape[0])
+        H = self._pad(H)
         out = ctypes.c_double(0.0)
         g = self._geom(H.shape[0], W.shape[0])
         _lib.check(self._lib.tnmf_hip_energy(self._ctx, ctypes.byref(g), _ptr(self._V_dev), _ptr(W), _ptr(H),
@@ -327,6 +360,11 @@ class HIP_Backend(Backend):
             return
         self._check_W(W)
         self._check_H(Hs, W.shape[0])
+        if self._mode != 0:
+            # padded modes: gradients on the padded tensor, folded back, then the elementwise MU kernel
+            neg, pos = self.reconstruction_gradient_H(V, W, H, s)
+            self.multiplicative_update(Hs, neg, pos, eps + (sparsity if sparsity > 0 else 0.))
+            return
         g = self._geom(Hs.shape[0], W.shape[0])
         Rs = self._R_scratch[ls]
         r_valid = 0

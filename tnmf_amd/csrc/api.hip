@@ -317,6 +317,20 @@ int tnmf_hip_convolve_multi_1d(tnmf_hip_ctx *ctx, int dtype, int ndim, size_t ro
     return launch_convolve_axis(ctx, dtype, tmp, out, rows * (size_t)shape[0], shape[1], 1, kernel1, len1, s);
 }
 
+int tnmf_hip_pad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *H, void *Hpad, void *stream) {
+    ENTER(ctx, geom);
+    if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
+    if (g.N > 0 && (!H || !Hpad)) return TNMF_E_NULL;
+    return launch_pad_fold(ctx, g, dtype, mode, false, H, Hpad, s);
+}
+
+int tnmf_hip_fold_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *Gpad, void *G, void *stream) {
+    ENTER(ctx, geom);
+    if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
+    if (g.N > 0 && (!Gpad || !G)) return TNMF_E_NULL;
+    return launch_pad_fold(ctx, g, dtype, mode, true, Gpad, G, s);
+}
+
 int tnmf_hip_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, void *H_inout,
                       void *R_scratch, int r_is_valid, double eps, double sparsity, void *stream) {
     ENTER(ctx, geom);

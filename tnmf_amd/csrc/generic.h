@@ -25,3 +25,6 @@ int launch_half_sqdiff(const tnmf_hip_ctx *ctx, int dtype, const void *V, const 
                        double *out_dev, hipStream_t s);
 int launch_convolve_axis(const tnmf_hip_ctx *ctx, int dtype, const void *in, void *out, size_t rows, int len,
                          int inner, const double *kernel_host, int ntaps, hipStream_t s);
+// reconstruction modes: pad activations (fold == false) / fold the gradient back (fold == true); mode = TNMF_MODE_*
+int launch_pad_fold(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, int mode, bool fold, const void *in, void *out,
+                    hipStream_t s);

@@ -555,3 +555,93 @@ int launch_convolve_axis(const tnmf_hip_ctx *ctx, int dtype, const void *in, voi
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// reconstruction modes: pad the activations / fold the gradient (reference: backends/_PyTorchBackend.py:42-52)
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+// activation index copied to padded position j of one axis (-1: a zero); S = activation length, a = atom length
+__device__ __forceinline__ int pad_src(int j, int S, int a, int mode) {
+    const int l = a - 1;
+    if (mode == TNMF_MODE_FULL) {
+        const int u = j - l;
+        return (u >= 0 && u < S) ? u : -1;
+    }
+    if (j >= l) return j - l;
+    return mode == TNMF_MODE_CIRCULAR ? S - l + j : l - j;   // wrap / mirror (without repeating the edge)
+}
+
+// second padded position (besides u + a - 1) that copies activation u, or -1
+__device__ __forceinline__ int pad_dup(int u, int S, int a, int mode) {
+    const int l = a - 1;
+    if (mode == TNMF_MODE_CIRCULAR) return u >= S - l ? u - (S - l) : -1;
+    if (mode == TNMF_MODE_REFLECT) return (u >= 1 && u <= l) ? l - u : -1;
+    return -1;
+}
+
+template <typename T>
+__global__ void k_pad_H(size_t rows, int Sy, int Sx, int Ay, int Ax, int Py, int Px, int mode,
+                        const T *__restrict__ H, T *__restrict__ Hp) {
+    const size_t total = rows * (size_t)Py * Px;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int jx = (int)(e % Px);
+        const size_t rest = e / Px;
+        const int jy = (int)(rest % Py);
+        const size_t r = rest / Py;
+        const int uy = Py == 1 ? 0 : pad_src(jy, Sy, Ay, mode);
+        const int ux = pad_src(jx, Sx, Ax, mode);
+        Hp[e] = (uy >= 0 && ux >= 0) ? H[(r * Sy + uy) * Sx + ux] : T(0);
+    }
+}
+
+template <typename T>
+__global__ void k_fold_H(size_t rows, int Sy, int Sx, int Ay, int Ax, int Py, int Px, int mode,
+                         const T *__restrict__ Gp, T *__restrict__ G) {
+    const size_t total = rows * (size_t)Sy * Sx;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int ux = (int)(e % Sx);
+        const size_t rest = e / Sx;
+        const int uy = (int)(rest % Sy);
+        const size_t r = rest / Sy;
+        const int jy[2] = {Py == 1 ? 0 : uy + Ay - 1, Py == 1 ? -1 : pad_dup(uy, Sy, Ay, mode)};
+        const int jx[2] = {ux + Ax - 1, pad_dup(ux, Sx, Ax, mode)};
+        T acc = T(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                if (jy[a] >= 0 && jx[b] >= 0) acc += Gp[(r * Py + jy[a]) * Px + jx[b]];
+        G[e] = acc;
+    }
+}
+
+}  // namespace
+
+// shift length of one axis for a mode (reference: backends/_Backend.py:60-73)
+static inline int mode_shift(int d, int a, int mode) {
+    return mode == TNMF_MODE_VALID ? d + a - 1 : (mode == TNMF_MODE_FULL ? d - a + 1 : d);
+}
+
+int launch_pad_fold(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, int mode, bool fold, const void *in, void *out,
+                    hipStream_t s) {
+    const int Sy = g.Dy == 1 && g.Ay == 1 ? 1 : mode_shift(g.Dy, g.Ay, mode), Sx = mode_shift(g.Dx, g.Ax, mode);
+    if (Sy < 1 || Sx < 1 || g.Ay - 1 > Sy || g.Ax - 1 > Sx) return TNMF_E_GEOM;
+    const size_t rows = (size_t)g.N * g.M;
+    const size_t total = rows * (fold ? (size_t)Sy * Sx : (size_t)g.Hy * g.Hx);
+    if (total == 0) return TNMF_OK;
+    const int grid = grid_for(total, ctx);
+#define LAUNCH_PF(K_, T_)                                                                                     \
+    hipLaunchKernelGGL(K_<T_>, dim3(grid), dim3(kBlock), 0, s, rows, Sy, Sx, g.Ay, g.Ax, g.Hy, g.Hx, mode,    \
+                       (const T_ *)in, (T_ *)out)
+    if (fold) {
+        if (dtype == 0) LAUNCH_PF(k_fold_H, float); else LAUNCH_PF(k_fold_H, double);
+    } else {
+        if (dtype == 0) LAUNCH_PF(k_pad_H, float); else LAUNCH_PF(k_pad_H, double);
+    }
+#undef LAUNCH_PF
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}

@@ -12,6 +12,7 @@ primitives_<case>.npz   inputs (V, W, H in float64) and outputs of the *genuine*
                         (pins the H-then-W draw order of backends/_Backend.py:92-95).
                         The reference's tests use this backend as their expected-factorisation fixture
                         (tnmf/tests/test_backends.py:53-56, test_minibatch.py:85-88).
+modes_<mode>_<case>.npz the same primitives for reconstruction modes 'full', 'circular', 'reflect'
 racoon_rgb_76x102.npz   the uint8 image behind tnmf/tests/test_backends.py:32-33 and test_sparsity_inhibition.py:55-56
                         (scipy's sample image `face`, PIL-resized to 0.1 scale exactly as utils/data_loading.py:8-12 does)
 racoon_gray_patches.npz the 768 uint8 32x32 patches behind tnmf/tests/test_minibatch.py:35-45 / test_stream.py:29-39
@@ -81,6 +82,35 @@ def make_primitives():
         print(name, 'E =', E)
 
 
+def make_mode_primitives():
+    """Same outputs for the non-'valid' reconstruction modes (padding table: backends/_PyTorchBackend.py:42-52)."""
+    import torch
+    Backend = reference_backend()
+    cases = {'1d': (3, 2, (17,), 3, (5,), (1, 3)), '2d': (2, 2, (13, 16), 3, (4, 5), None)}
+    for mode in ('full', 'circular', 'reflect'):
+        for name, (N, C, D, M, A, sl) in cases.items():
+            k = len(A)
+            gen = np.random.default_rng(sum(map(ord, mode + name)))
+            V = gen.random((N, C) + D)
+            be = Backend(reconstruction_mode=mode)
+            np.random.seed(42)
+            W0, H0 = be.initialize(V, A, M, None, tuple(range(-k, 0)))
+            W = gen.random((M, C) + A)
+            W /= W.sum(axis=tuple(range(-k, 0)), keepdims=True)
+            H = gen.random(tuple(H0.shape))
+            Wt, Ht = torch.from_numpy(W), torch.from_numpy(H)
+            s = slice(None) if sl is None else slice(*sl)
+            R = be.reconstruct(Wt, Ht)
+            nH, pH = be.reconstruction_gradient_H(V, Wt, Ht, s)
+            nW, pW = be.reconstruction_gradient_W(V, Wt, Ht, s)
+            np.savez_compressed(
+                os.path.join(OUT, f'modes_{mode}_{name}.npz'),
+                V=V, W=W, H=H, slice=np.array([-1, -1] if sl is None else sl),
+                R=R.numpy(), neg_H=nH.numpy(), pos_H=pH.numpy(), neg_W=nW.numpy(), pos_W=pW.numpy(),
+                energy=np.float64(be.reconstruction_energy(V, Wt, Ht)), init_H_shape=np.array(H0.shape))
+            print(mode, name, 'H', tuple(H0.shape))
+
+
 def load_face():
     with open(FACE_DAT, 'rb') as f:
         raw = bz2.decompress(f.read())
@@ -110,5 +140,6 @@ def make_racoon():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     make_primitives()
+    make_mode_primitives()
     make_racoon()
     print('written to', OUT)
