@@ -348,6 +348,69 @@ def correlate_H_with_shiftsum(X: np.ndarray, H: np.ndarray, A: Sequence[int]) ->
 
 
 # ----------------------------------------------------------------------------------------------------------
+# FFT form of the three primitives ('valid' mode) -- restatement of the reference's default backend 'numpy_fft'
+# (backends/NumPy_FFT.py:16-40 `_fft_convolve`, parameter tables backends/_NumPyFFTBackend.py:43-88).  Only used as the
+# second, stronger CPU comparator of bench.py; pinned by the same golden vectors.
+# ----------------------------------------------------------------------------------------------------------
+def _fft_shape(sample_shape, transform_shape):
+    from scipy.fft import next_fast_len
+    return tuple(next_fast_len(int(d + t - 1)) for d, t in zip(sample_shape, transform_shape))
+
+
+def _fft_convolve(arrs, arr2, subscripts, slices, axes, fft_shape, correlate):
+    """rfftn both operands, contract per frequency, irfftn, slice (NumPy_FFT.py:29-40)."""
+    from scipy.fft import irfftn, rfftn
+    c2 = np.flip(arr2, axis=axes) if correlate else arr2
+    f2 = rfftn(c2, axes=axes, s=fft_shape, workers=-1)
+    out = []
+    for arr in arrs:
+        f1 = rfftn(arr, axes=axes, s=fft_shape, workers=-1)
+        fr = np.einsum(subscripts, f1, f2, optimize=True)
+        out.append(irfftn(fr, axes=axes, s=fft_shape, workers=-1)[slices].copy())
+    return out
+
+
+def reconstruct_fft(W, H):
+    k = W.ndim - 2
+    A = W.shape[2:]
+    D = tuple(h - a + 1 for h, a in zip(H.shape[2:], A))
+    sl = (slice(None), slice(None)) + tuple(slice(a - 1, a - 1 + d) for a, d in zip(A, D))
+    return _fft_convolve((H,), W, 'nm...,mc...->nc...', sl, _shift_axes(k), _fft_shape(D, H.shape[2:]), False)[0]
+
+
+def gradient_H_fft(V, W, H, s=slice(None)):
+    k = W.ndim - 2
+    Hs = H[s]
+    D = V.shape[2:]
+    sl = (slice(None), slice(None)) + tuple(slice(0, t) for t in Hs.shape[2:])
+    R = reconstruct_fft(W, Hs)
+    neg, pos = _fft_convolve((V[s], R), W, 'nc...,mc...->nm...', sl, _shift_axes(k), _fft_shape(D, Hs.shape[2:]), True)
+    return neg, pos
+
+
+def gradient_W_fft(V, W, H, s=slice(None)):
+    k = W.ndim - 2
+    A = W.shape[2:]
+    Hs = H[s]
+    D = V.shape[2:]
+    lower = tuple(min(d, t) - 1 for d, t in zip(D, Hs.shape[2:]))
+    sl = (slice(None), slice(None)) + tuple(slice(lo, lo + a) for lo, a in zip(lower, A))
+    R = reconstruct_fft(W, Hs)
+    neg, pos = _fft_convolve((V[s], R), Hs, 'nc...,nm...->mc...', sl, _shift_axes(k), _fft_shape(D, Hs.shape[2:]), True)
+    return neg, pos
+
+
+def mu_iteration_fft(V, W, H, eps: float = EPS, sparsity: float = 0.):
+    """One full-batch MU iteration with the FFT primitives (TransformInvariantNMF.py:334-340 over 'numpy_fft')."""
+    k = W.ndim - 2
+    neg, pos = gradient_H_fft(V, W, H)
+    multiplicative_update(H, neg.astype(H.dtype, copy=False), pos.astype(H.dtype, copy=False), eps, sparsity)
+    neg, pos = gradient_W_fft(V, W, H)
+    multiplicative_update(W, neg.astype(W.dtype, copy=False), pos.astype(W.dtype, copy=False), eps,
+                          normalization_axes=tuple(range(-k, 0)))
+
+
+# ----------------------------------------------------------------------------------------------------------
 # lateral inhibition helper and the elementwise multiplicative update
 # ----------------------------------------------------------------------------------------------------------
 def convolve_multi_1d(arr: np.ndarray, kernels: Sequence[np.ndarray], axes: Iterable[int]) -> np.ndarray:

@@ -43,6 +43,15 @@ def test_primitives_match_reference_backend(path):
     np.testing.assert_allclose(orc.reconstruct_shiftsum(W, H), g['R'], **tol)
     np.testing.assert_allclose(orc.correlate_with_W_shiftsum(W, V[s]), g['neg_H'], **tol)
     np.testing.assert_allclose(orc.correlate_H_with_shiftsum(V[s], H[s], A), g['neg_W'], **tol)
+    # the FFT form (the reference's default backend numpy_fft), bench.py's second CPU comparator
+    if s == slice(None):
+        np.testing.assert_allclose(orc.reconstruct_fft(W, H), g['R'], rtol=1e-9, atol=1e-10)
+        neg, pos = orc.gradient_H_fft(V, W, H)
+        np.testing.assert_allclose(neg, g['neg_H'], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(pos, g['pos_H'], rtol=1e-9, atol=1e-10)
+        neg, pos = orc.gradient_W_fft(V, W, H)
+        np.testing.assert_allclose(neg, g['neg_W'], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(pos, g['pos_W'], rtol=1e-9, atol=1e-9)
     # third: the C flavour (oracle/tnmf_oracle_c.c), in float64 and in float32 (double accumulation)
     np.testing.assert_allclose(orc.reconstruct(W, H, 'c'), g['R'], **tol)
     neg, pos = orc.gradient_H(V, W, H, s, 'c')
