@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TNMF_HIP_ABI_VERSION 1
+#define TNMF_HIP_ABI_VERSION 2
 
 enum {
     TNMF_OK = 0,
@@ -48,8 +48,10 @@ typedef struct {
     int dtype; /* 0 = f32, 1 = f64 */
 } tnmf_hip_geom;
 
-/* Kernel family selection (tnmf_hip_ctx_set_path): AUTO picks the MFMA kernels where the shape allows. */
-enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2 };
+/* Kernel family selection (tnmf_hip_ctx_set_path): AUTO picks the MFMA kernels where the shape allows.  FFT is the
+ * frequency-domain formulation (the algorithm of the reference's default backend, tnmf/backends/NumPy_FFT.py:16-40):
+ * float32 2-D problems with shift shapes up to 576, float64 up to 96. */
+enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_FFT = 3 };
 
 int tnmf_hip_abi_version(void);
 const char *tnmf_hip_strerror(int code);
@@ -60,8 +62,14 @@ int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx);
 /* Pre-size the scratch for `geom` so that later calls allocate nothing (graph-capture safe). */
 int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom);
 int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path);
-/* Name of the kernel family the last primitive call on this ctx dispatched to ("generic", "mfma", ...). */
+/* Name of the kernel family the last primitive call on this ctx dispatched to ("generic", "mfma", "fft"). */
 const char *tnmf_hip_ctx_last_path(const tnmf_hip_ctx *ctx);
+/* FFT family only: the library may keep the row spectra of the activations H it transformed or updated last and
+ * reuse them while the same H pointer comes back (the reference's NumPy_CachingFFT.py:22-140 caches spectra the same
+ * way).  Off by default.  A caller that enables it vouches that H changes only through this library, and calls
+ * tnmf_hip_ctx_invalidate() after writing H by any other means. */
+int tnmf_hip_ctx_set_cache(tnmf_hip_ctx *ctx, int enable);
+int tnmf_hip_ctx_invalidate(tnmf_hip_ctx *ctx);
 
 /* ---- primitives: API-parity path --------------------------------------------------------------------------- */
 

@@ -209,7 +209,7 @@ def test_known_answer_stream_f64():
     assert np.isclose(nmf._energy_function(), 96.7375921)         # tnmf/tests/test_stream.py:25
 
 
-@pytest.mark.parametrize('path', PATHS)
+@pytest.mark.parametrize('path', PATHS + ['fft'])
 @pytest.mark.parametrize('N,C,D,M,A', [(8, 1, (64, 64), 8, (9, 9)), (4, 1, (96, 80), 32, (12, 12)), (3, 3, (48, 48), 32, (12, 12))])
 def test_f32_loop_parity_with_f64_oracle(N, C, D, M, A, path):
     """North-star criterion: W within 1e-5 (max-relative) of the float64 reference after a fixed 5 iterations."""
@@ -223,7 +223,9 @@ def test_f32_loop_parity_with_f64_oracle(N, C, D, M, A, path):
     np.random.seed(42)
     ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c').fit(V.astype(np.float64), n_iterations=5)
     assert relmax(nmf.W, ref.W) < 1e-5
-    assert relmax(nmf.H, ref.H) < 1e-4
+    # float32 transforms carry an absolute error of ~1e-7 of the largest gradient entry into every entry, so small
+    # activations are relatively less exact in the FFT family (the reference's FFT backends share this in float32)
+    assert relmax(nmf.H, ref.H) < (5e-3 if path == 'fft' else 1e-4)
     assert abs(nmf._energy_function() - ref.energy()) / ref.energy() < 1e-5
 
 
@@ -259,6 +261,90 @@ def test_matrix_core_kernels_at_baseline_sizes(C, D, M, A):
         out[path] = [be.to_ndarray(x) for x in (R, nH, pH, nW, pW, Hf)]
     for got, want in zip(out['mfma'], out['generic']):
         assert relmax(got, want) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# FFT kernel family (path='fft'): the frequency-domain formulation must give the same numbers as the direct one
+# ---------------------------------------------------------------------------------------------------------------
+FFT_SHAPES = [
+    # N, C, D, M, A, dtypes      transform lengths (y, x)
+    (3, 1, (37, 45), 16, (9, 9), 'df'),        # 48, 64
+    (2, 3, (33, 31), 7, (5, 8), 'df'),         # 48, 48
+    (2, 2, (20, 70), 33, (16, 16), 'df'),      # 48, 96
+    (2, 1, (5, 6), 2, (5, 6), 'df'),           # 32, 32 (atom as large as the sample)
+    (1, 1, (64, 64), 32, (12, 12), 'df'),      # 96, 96
+    (5, 5, (24, 40), 3, (3, 7), 'df'),         # 32, 48; more channels than one register group
+    (2, 1, (128, 128), 16, (9, 9), 'f'),       # 144, 144
+    (2, 3, (100, 170), 8, (12, 12), 'f'),      # 144, 192
+    (1, 3, (256, 200), 8, (12, 12), 'f'),      # 288, 288
+    (1, 1, (300, 500), 4, (16, 16), 'f'),      # 384, 576
+]
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-10), (np.float32, 2e-5)], ids=['f64', 'f32'])
+@pytest.mark.parametrize('shape', FFT_SHAPES, ids=[f'{s[0]}x{s[1]}x{"x".join(map(str, s[2]))}_m{s[3]}_a{"x".join(map(str, s[4]))}' for s in FFT_SHAPES])
+def test_fft_family_against_oracle(shape, dtype, tol):
+    N, C, D, M, A, kinds = shape
+    if ('d' if dtype == np.float64 else 'f') not in kinds:
+        pytest.skip('float64 transforms are instantiated up to length 96')
+    rng = np.random.default_rng(N * 1000 + M)
+    V = rng.random((N, C) + D)
+    Wn = rng.random((M, C) + A)
+    Wn /= Wn.sum(axis=(-2, -1), keepdims=True)
+    Hn = rng.random((N, M) + tuple(d + a - 1 for d, a in zip(D, A)))
+    be = make_backend(V.astype(dtype), A, M, 'fft')
+    W, H = dev(Wn, dtype), dev(Hn, dtype)
+    assert relmax(be.to_ndarray(be.reconstruct(W, H)), orc.reconstruct(Wn, Hn, 'c')) < tol
+    assert be.last_path == 'fft'
+    for s in (slice(None), slice(N - 1, N)):
+        on, op = orc.gradient_H(V, Wn, Hn, s, 'c')
+        neg, pos = be.reconstruction_gradient_H(V, W, H, s)
+        assert tuple(neg.shape) == on.shape
+        assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+        on, op = orc.gradient_W(V, Wn, Hn, s, 'c')
+        neg, pos = be.reconstruction_gradient_W(V, W, H, s)
+        assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+        assert be.last_path == 'fft'
+    # fused half steps (these keep the row spectra of H cached between the calls)
+    Hf = dev(Hn, dtype)
+    be.fused_update_H(V, W, Hf, slice(None), sparsity=0.1, eps=1e-9)
+    on, op = orc.gradient_H(V, Wn, Hn, slice(None), 'c')
+    Hnew = Hn * on / (op + 1e-9 + 0.1)
+    assert relmax(be.to_ndarray(Hf), Hnew) < 2 * tol
+    Wf = dev(Wn, dtype)
+    be.fused_update_W(V, Wf, Hf, slice(None), eps=1e-9)       # uses the cached spectra of the updated H
+    on, op = orc.gradient_W(V, Wn, Hnew, slice(None), 'c')
+    Wo = Wn * on / (op + 1e-9)
+    Wo /= Wo.sum(axis=(-2, -1), keepdims=True)
+    assert relmax(be.to_ndarray(Wf), Wo) < 2 * tol
+    be.fused_update_H(V, Wf, Hf, slice(None), sparsity=0., eps=1e-9)   # cached spectra again, new W
+    on, op = orc.gradient_H(V, Wo, Hnew, slice(None), 'c')
+    assert relmax(be.to_ndarray(Hf), Hnew * on / (op + 1e-9)) < 4 * tol
+
+
+@pytest.mark.parametrize('C,D,M,A', BASELINE_SHAPES, ids=['config2', 'config3', 'config4', 'config5'])
+def test_fft_family_at_baseline_sizes(C, D, M, A):
+    rng = np.random.default_rng(5)
+    V = rng.random((2, C) + D).astype(np.float32)
+    Wn = rng.random((M, C) + A).astype(np.float32)
+    Hn = rng.random((2, M) + tuple(d + a - 1 for d, a in zip(D, A))).astype(np.float32)
+    out = {}
+    for path in ('fft', 'generic'):
+        be = make_backend(V, A, M, path)
+        W, H = dev(Wn, np.float32), dev(Hn, np.float32)
+        R = be.reconstruct(W, H)
+        assert be.last_path == path
+        nH, pH = be.reconstruction_gradient_H(V, W, H)
+        nW, pW = be.reconstruction_gradient_W(V, W, H)
+        assert be.last_path == path
+        Hf = H.clone()
+        be.fused_update_H(V, W, Hf, slice(None), sparsity=0.05, eps=1e-9)
+        out[path] = [be.to_ndarray(x) for x in (R, nH, pH, nW, pW, Hf)]
+    for got, want in zip(out['fft'][:5], out['generic'][:5]):
+        assert relmax(got, want) < 2e-5
+    # the updated H divides two gradients that are tiny at the borders of the shift range (few overlapping taps), where
+    # the absolute float32 transform error (~1e-7 of the largest entry) is relatively large
+    assert relmax(out['fft'][5], out['generic'][5]) < 2e-3
 
 
 MODE_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'modes_*.npz')))

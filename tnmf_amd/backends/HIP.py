@@ -55,7 +55,8 @@ class HIP_Backend(Backend):
            pad the activations (tnmf_hip_pad_H), run the same 'valid' kernels on the padded tensor and fold the H gradient
            back (tnmf_hip_fold_H) -- the padding table of the reference's _PyTorchBackend.py:42-52
     device : CUDA/HIP device index or ``torch.device``; default: the current device
-    path : ``'auto'`` | ``'generic'`` | ``'mfma'`` -- kernel family (``'auto'`` = MFMA where the shape allows)
+    path : ``'auto'`` | ``'generic'`` | ``'mfma'`` | ``'fft'`` -- kernel family (``'auto'`` = MFMA where the shape
+           allows; ``'fft'`` = frequency-domain formulation, the algorithm of the reference's default backend)
     init : ``'reference'`` draws H then W from the global legacy NumPy RNG exactly like the reference
            (_Backend.py:92-95); ``'device'`` draws them with the device generator (fast, not seed-compatible)
     process_group : a ``torch.distributed`` group, ``True`` for the default group, or ``None``.  With a group the
@@ -82,6 +83,10 @@ class HIP_Backend(Backend):
         self._ctx = ctypes.c_void_p()
         _lib.check(self._lib.tnmf_hip_ctx_create(self._device.index, ctypes.byref(self._ctx)), 'tnmf_hip_ctx_create')
         _lib.check(self._lib.tnmf_hip_ctx_set_path(self._ctx, _lib.PATHS[path]), 'tnmf_hip_ctx_set_path')
+        # FFT family: the library may reuse the row spectra of H between the fused half steps (it updated H itself);
+        # every other entry point below declares H as possibly changed first (_foreign_H).
+        _lib.check(self._lib.tnmf_hip_ctx_set_cache(self._ctx, 1 if reconstruction_mode == 'valid' else 0),
+                   'tnmf_hip_ctx_set_cache')
 
         self._group = None
         self._rank, self._world = 0, 1
@@ -119,6 +124,10 @@ class HIP_Backend(Backend):
     @property
     def last_path(self) -> str:
         return self._lib.tnmf_hip_ctx_last_path(self._ctx).decode()
+
+    def _foreign_H(self) -> None:
+        """H of the coming call may have been written by someone else: drop cached spectra (FFT family)."""
+        self._lib.tnmf_hip_ctx_invalidate(self._ctx)
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
@@ -207,6 +216,7 @@ class HIP_Backend(Backend):
             raise NotImplementedError('the hip backend supports 1 or 2 shift dimensions')
         self._torch_dtype, self._dtype_code = _DTYPES[V.dtype]
         N = self.n_samples
+        self._foreign_H()
         n0, n1 = self._shard = sharding.shard_bounds(N, self._rank, self._world)
         with torch.cuda.device(self._device):
             self._V_dev = torch.as_tensor(np.ascontiguousarray(V[n0:n1])).to(self._device)
@@ -237,6 +247,7 @@ class HIP_Backend(Backend):
     def reconstruct(self, W: torch.Tensor, H: torch.Tensor) -> torch.Tensor:
         """R = H (*) W, 'valid' part (reference: NumPy.py:122-132) -> tnmf_hip_reconstruct."""
         self._check_W(W)
+        self._foreign_H()
         if not H.is_contiguous():
             H = H.contiguous()
         self._check_H(H, W.shape[0])
@@ -251,6 +262,7 @@ class HIP_Backend(Backend):
         """(neg, pos) of H[s]'s shape (reference: NumPy.py:93-120) -> tnmf_hip_grad_H.  `V` is the array given to
         initialize(); the device-resident copy is used (precedent: NumPy_CachingFFT.py:259,273)."""
         self._check_W(W)
+        self._foreign_H()
         ls = self._local(s)
         Hs, Vs = H[ls], self._V_dev[ls]
         self._check_H(Hs, W.shape[0])
@@ -285,6 +297,7 @@ class HIP_Backend(Backend):
     def reconstruction_gradient_W(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone):
         """(neg, pos) of W's shape (reference: NumPy.py:69-91) -> tnmf_hip_grad_W_fused; summed over the ranks of
         the process group (one all-reduce of the contiguous [neg | pos] buffer)."""
+        self._foreign_H()
         negpos = self._local_grad_W(W, H, s)
         self._all_reduce(negpos)
         return negpos[0], negpos[1]
@@ -292,6 +305,7 @@ class HIP_Backend(Backend):
     def reconstruction_energy(self, V, W: torch.Tensor, H: torch.Tensor) -> float:
         """1/2 sum (V - R)^2 (reference: _Backend.py:127-130) -> tnmf_hip_energy (+ all-reduce)."""
         self._check_W(W)
+        self._foreign_H()
         self._check_H(H, W.shape[0])
         H = self._pad(H)
         out = ctypes.c_double(0.0)

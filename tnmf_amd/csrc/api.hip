@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <new>
 
+#include "fft.h"
 #include "generic.h"
 #include "mfma.h"
 
@@ -83,7 +84,7 @@ inline char *ws_at(tnmf_hip_ctx *ctx, size_t off) { return static_cast<char *>(c
 enum Prim { kReconstruct, kCorrW, kCorrH };
 
 bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
-    if (ctx->path == TNMF_PATH_GENERIC) return false;
+    if (ctx->path == TNMF_PATH_GENERIC || ctx->path == TNMF_PATH_FFT) return false;
     switch (prim) {
         case kReconstruct: return mfma_has_reconstruct(g, dtype);
         case kCorrW: return mfma_has_corr_W(g, dtype);
@@ -110,6 +111,7 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
 
 int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
+    if (ctx->path == TNMF_PATH_FFT) return fft_reconstruct(ctx, g, dtype, W, H, R, s);
     if (use_mfma(ctx, g, dtype, kReconstruct)) {
         ctx->last_path = "mfma";
         return mfma_reconstruct(ctx, g, (const float *)W, (const float *)H, (float *)R, s);
@@ -122,6 +124,8 @@ int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, co
 int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *Hio,
               void *neg, void *pos, bool fused, double reg, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
+    if (ctx->path == TNMF_PATH_FFT)
+        return fused ? fft_update_H(ctx, g, dtype, V, R, W, Hio, reg, s) : fft_grad_H(ctx, g, dtype, V, R, W, neg, pos, s);
     if (use_mfma(ctx, g, dtype, kCorrW)) {
         ctx->last_path = "mfma";
         return mfma_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio, (float *)neg,
@@ -142,6 +146,7 @@ int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, con
         TNMF_HIP_TRY(hipMemsetAsync(pos, 0, (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype), s));
         return TNMF_OK;
     }
+    if (ctx->path == TNMF_PATH_FFT) return fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, s);
     if (use_mfma(ctx, g, dtype, kCorrH)) {
         ctx->last_path = "mfma";
         P = mfma_corr_H_chunks(ctx, g);
@@ -193,6 +198,7 @@ int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out) {
     }
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
+    ctx->fft = FftState();
     *out = ctx;
     return TNMF_OK;
 }
@@ -200,9 +206,12 @@ int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out) {
 int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx) {
     if (!ctx) return TNMF_OK;
     int rc = TNMF_OK;
-    if (ctx->ws) {
+    if (ctx->ws || ctx->fft.ws) {
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
+    }
+    fft_release(ctx);
+    if (ctx->ws) {
         const hipError_t e = hipFree(ctx->ws);
         if (e != hipSuccess) rc = (int)e;
     }
@@ -219,8 +228,21 @@ int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom) {
 
 int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path) {
     if (!ctx) return TNMF_E_NULL;
-    if (path < TNMF_PATH_AUTO || path > TNMF_PATH_MFMA) return TNMF_E_UNSUPPORTED;
+    if (path < TNMF_PATH_AUTO || path > TNMF_PATH_FFT) return TNMF_E_UNSUPPORTED;
     ctx->path = path;
+    return TNMF_OK;
+}
+
+int tnmf_hip_ctx_set_cache(tnmf_hip_ctx *ctx, int enable) {
+    if (!ctx) return TNMF_E_NULL;
+    ctx->fft.cache_enabled = enable != 0;
+    ctx->fft.T_valid = false;
+    return TNMF_OK;
+}
+
+int tnmf_hip_ctx_invalidate(tnmf_hip_ctx *ctx) {
+    if (!ctx) return TNMF_E_NULL;
+    fft_invalidate(ctx);
     return TNMF_OK;
 }
 
@@ -271,6 +293,7 @@ int tnmf_hip_mu_update(tnmf_hip_ctx *ctx, int dtype, void *arr, const void *neg,
     if (dtype != 0 && dtype != 1) return TNMF_E_DTYPE;
     if (n_elems > 0 && (!arr || !neg || !pos)) return TNMF_E_NULL;
     TNMF_HIP_TRY(hipSetDevice(ctx->device));
+    fft_invalidate(ctx);   // arr may be (part of) the activations whose row spectra are cached
     return launch_mu_update(ctx, dtype, arr, neg, pos, reg, n_elems, static_cast<hipStream_t>(stream));
 }
 

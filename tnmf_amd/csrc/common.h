@@ -15,14 +15,26 @@ struct Geo {
     int Hy, Hx;  // shift (activation) shape: D + A - 1
 };
 
+// state of the FFT kernel family (fft.hip): its own workspace and the cache of the row spectra of H
+struct FftState {
+    void *ws;
+    size_t ws_bytes;
+    bool cache_enabled;      // the caller vouches that H only changes through this library (tnmf_hip_ctx_set_cache)
+    bool T_valid;            // the workspace holds the row spectra of T_owner for T_geo / T_dtype
+    const void *T_owner;
+    Geo T_geo;
+    int T_dtype;
+};
+
 struct tnmf_hip_ctx {
     int device;
     int num_cu;
     int path;               // TNMF_PATH_*
-    const char *last_path;  // "generic" | "mfma"
+    const char *last_path;  // "generic" | "mfma" | "fft"
     int ablate;             // diagnostic only (env TNMF_HIP_ABLATE at ctx creation): kernels skip phases; results wrong
     void *ws;               // scratch: [R | split-K partials | reduction words]
     size_t ws_bytes;
+    FftState fft;
 };
 
 #define TNMF_HIP_TRY(expr)                          \

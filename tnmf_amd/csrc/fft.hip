@@ -1,0 +1,416 @@
+// fft.hip -- host side of the FFT kernel family: transform-length choice, workspace layout and the kernel sequences of
+// the three primitives (see fft.h).  The kernels live in fft_kernels.h / fft_len.hip.
+//
+// 'valid' mode in the frequency domain (circular transforms of length L >= H = D + A - 1 per shift axis, so nothing
+// that is kept ever wraps):
+//   reconstruct  R   = crop_[A-1, A-1+D) ( ifft( sum_m H^ W^ ) )                       NumPy.py:122-132
+//   H gradient   neg = crop_[0, H)       ( ifft( sum_c V^ Wf^ ) ),  Wf = W flipped     NumPy.py:93-120
+//   W gradient   neg[a] = c[A-1-a],  c = crop_[0, A) ( ifft( sum_n H^ conj(V^) ) )     NumPy.py:69-91
+// pos is the same with R in place of V.  1/(Ly*Lx) is folded into the W spectra (and into the partial-sum kernel of
+// the W gradient), so no separate scaling pass exists.
+#include <cstdlib>
+
+#include "fft.h"
+#include "fft_engine.h"
+
+namespace {
+
+const int kLens[] = {32, 48, 64, 96, 144, 192, 288, 384, 576};
+
+int pick_len(int h, int dtype) {
+    for (int L : kLens)
+        if (L >= h && (dtype == 0 || L <= 96)) return L;
+    return 0;
+}
+
+fft_run_fn lookup(int L) {
+    switch (L) {
+        case 32: return fft_run_32;
+        case 48: return fft_run_48;
+        case 64: return fft_run_64;
+        case 96: return fft_run_96;
+        case 144: return fft_run_144;
+        case 192: return fft_run_192;
+        case 288: return fft_run_288;
+        case 384: return fft_run_384;
+        case 576: return fft_run_576;
+        default: return nullptr;
+    }
+}
+
+// workspace layout, in bytes
+struct Lay {
+    int Ly, Lx, KX, KXP, ngroups, nper;
+    fft_run_fn rowf, colf;
+    size_t csz;  // bytes of one complex element
+    size_t T, Tn, Tp, SV, SR, Ts, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total;
+};
+
+bool make_layout(const Geo &g, int dtype, Lay *l) {
+    l->Ly = pick_len(g.Hy, dtype);
+    l->Lx = pick_len(g.Hx, dtype);
+    if (!l->Ly || !l->Lx) return false;
+    l->rowf = lookup(l->Lx);
+    l->colf = lookup(l->Ly);
+    l->KX = l->Lx / 2 + 1;
+    l->KXP = (int)align_up((size_t)l->KX, 16);
+    l->csz = dtype == 0 ? 8 : 16;
+    const int tiles = cdiv(l->KX, 16);
+    int ng = cdiv(2048, g.M * tiles);
+    if (ng > 16) ng = 16;
+    if (ng > g.N) ng = g.N;
+    if (ng < 1) ng = 1;
+    l->nper = cdiv(g.N > 0 ? g.N : 1, ng);
+    l->ngroups = cdiv(g.N > 0 ? g.N : 1, l->nper);
+    const size_t c = l->csz, kxp = (size_t)l->KXP;
+    const size_t nT = (size_t)g.N * g.M * g.Hy * kxp * c;
+    const size_t nS = (size_t)g.N * g.C * l->Ly * kxp * c;
+    const size_t nSW = (size_t)g.M * g.C * l->Ly * kxp * c;
+    size_t o = 0;
+    auto take = [&o](size_t bytes) {
+        const size_t at = o;
+        o += align_up(bytes, 256);
+        return at;
+    };
+    l->T = take(nT);
+    l->Tn = take(nT);
+    l->Tp = take(nT);
+    l->SV = take(nS);
+    l->SR = take(nS);
+    l->Ts = take((size_t)g.N * g.C * g.Dy * kxp * c);
+    l->SW = take(nSW);
+    l->SWf = take(nSW);
+    l->TW = take((size_t)2 * g.M * g.C * g.Ay * kxp * c);
+    l->Wt = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
+    l->Gn = take(nSW * l->ngroups);
+    l->Gp = take(nSW * l->ngroups);
+    l->Gs = take(nSW * 2);
+    l->Wo = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
+    l->total = o;
+    return true;
+}
+
+int ensure_ws(tnmf_hip_ctx *ctx, size_t bytes) {
+    FftState &f = ctx->fft;
+    if (bytes <= f.ws_bytes) return TNMF_OK;
+    if (f.ws) {
+        TNMF_HIP_TRY(hipDeviceSynchronize());
+        TNMF_HIP_TRY(hipFree(f.ws));
+        f.ws = nullptr;
+        f.ws_bytes = 0;
+    }
+    f.T_valid = false;
+    const size_t want = align_up(bytes, 1 << 20);
+    if (hipMalloc(&f.ws, want) != hipSuccess) {
+        (void)hipGetLastError();
+        return TNMF_E_WORKSPACE;
+    }
+    f.ws_bytes = want;
+    return TNMF_OK;
+}
+
+inline char *at(tnmf_hip_ctx *ctx, size_t off) { return static_cast<char *>(ctx->fft.ws) + off; }
+
+#define CHECK(rc_expr)                  \
+    do {                                \
+        const int _rc = (rc_expr);      \
+        if (_rc != TNMF_OK) return _rc; \
+    } while (0)
+
+// out0 = scale * W, out1 = scale * W flipped along both atom axes
+template <typename T>
+__global__ void k_fft_prep_W(const T *W, T *out0, T *out1, int planes, int Ay, int Ax, double scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, per = Ay * Ax;
+    if (i >= planes * per) return;
+    const int p = i / per, r = i - p * per, ay = r / Ax, ax = r - ay * Ax;
+    const T v = (T)(scale * (double)W[i]);
+    out0[i] = v;
+    out1[(long)p * per + (Ay - 1 - ay) * Ax + (Ax - 1 - ax)] = v;
+}
+
+// out = scale * sum over groups, in group order (deterministic)
+template <typename T>
+__global__ void k_fft_sum_groups(const cplx<T> *parts, cplx<T> *out, long count, int ngroups, double scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double re = 0, im = 0;
+    for (int gidx = 0; gidx < ngroups; ++gidx) {
+        const cplx<T> v = parts[gidx * count + i];
+        re += (double)v.x;
+        im += (double)v.y;
+    }
+    out[i] = {(T)(re * scale), (T)(im * scale)};
+}
+
+// neg/pos[m,c,a] = corr[m,c,A-1-a]  (the flip of NumPy.py:85,90)
+template <typename T>
+__global__ void k_fft_flip_out(const T *in, T *out, int planes, int Ay, int Ax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, per = Ay * Ax;
+    if (i >= planes * per) return;
+    const int p = i / per, r = i - p * per, ay = r / Ax, ax = r - ay * Ax;
+    out[i] = in[(long)p * per + (Ay - 1 - ay) * Ax + (Ax - 1 - ax)];
+}
+
+FftArgs base_args(const Geo &g, const Lay &l) {
+    FftArgs a = {};
+    a.KX = l.KX;
+    a.KXP = l.KXP;
+    a.N = g.N;
+    a.M = g.M;
+    a.C = g.C;
+    a.Hy = g.Hy;
+    return a;
+}
+
+// real planes [planes][rows][cols] (contiguous) -> full spectra
+int forward_planes(const Geo &g, const Lay &l, int dtype, const void *src, int planes, int rows, int cols, void *Ttmp,
+                   void *S, hipStream_t s) {
+    FftArgs a = base_args(g, l);
+    a.src0 = src;
+    a.dst0 = Ttmp;
+    a.planes = planes;
+    a.rows = rows;
+    a.cols = cols;
+    a.ld_src = cols;
+    a.ps_src = (long)rows * cols;
+    a.ps_dst = (long)rows * l.KXP;
+    CHECK(l.rowf(kFftRowsFwd, dtype, &a, s));
+    FftArgs b = base_args(g, l);
+    b.src0 = Ttmp;
+    b.dst0 = S;
+    b.planes = planes;
+    b.rows = rows;
+    return l.colf(kFftColsFwd, dtype, &b, s);
+}
+
+// W spectra (plain into SW, flipped into SWf), both scaled by 1/(Ly*Lx)
+int spectra_W(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *W, bool plain, bool flipped,
+              hipStream_t s) {
+    const int planes = g.M * g.C, per = g.Ay * g.Ax, n = planes * per;
+    const double scale = 1.0 / ((double)l.Ly * l.Lx);
+    char *wt = at(ctx, l.Wt);
+    const size_t half = (size_t)n * (l.csz / 2);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_fft_prep_W<float>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float *)W, (float *)wt,
+                           (float *)(wt + half), planes, g.Ay, g.Ax, scale);
+    else
+        hipLaunchKernelGGL(k_fft_prep_W<double>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const double *)W, (double *)wt,
+                           (double *)(wt + half), planes, g.Ay, g.Ax, scale);
+    TNMF_LAUNCH_CHECK();
+    if (plain) CHECK(forward_planes(g, l, dtype, wt, planes, g.Ay, g.Ax, at(ctx, l.TW), at(ctx, l.SW), s));
+    if (flipped) CHECK(forward_planes(g, l, dtype, wt + half, planes, g.Ay, g.Ax, at(ctx, l.TW), at(ctx, l.SWf), s));
+    return TNMF_OK;
+}
+
+bool T_is_current(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
+    const FftState &f = ctx->fft;
+    return f.cache_enabled && f.T_valid && f.T_owner == H && f.T_dtype == dtype && f.T_geo.N == g.N &&
+           f.T_geo.M == g.M && f.T_geo.C == g.C && f.T_geo.Dy == g.Dy && f.T_geo.Dx == g.Dx && f.T_geo.Ay == g.Ay &&
+           f.T_geo.Ax == g.Ax;
+}
+
+void T_mark(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
+    FftState &f = ctx->fft;
+    f.T_valid = f.cache_enabled;
+    f.T_owner = H;
+    f.T_geo = g;
+    f.T_dtype = dtype;
+}
+
+// row spectra of H into the workspace (skipped when the cache holds them)
+int rows_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *H, hipStream_t s) {
+    if (T_is_current(ctx, g, dtype, H)) return TNMF_OK;
+    FftArgs a = base_args(g, l);
+    a.src0 = H;
+    a.dst0 = at(ctx, l.T);
+    a.planes = g.N * g.M;
+    a.rows = g.Hy;
+    a.cols = g.Hx;
+    a.ld_src = g.Hx;
+    a.ps_src = (long)g.Hy * g.Hx;
+    a.ps_dst = (long)g.Hy * l.KXP;
+    CHECK(l.rowf(kFftRowsFwd, dtype, &a, s));
+    T_mark(ctx, g, dtype, H);
+    return TNMF_OK;
+}
+
+int prepare(tnmf_hip_ctx *ctx, const Geo &g, int dtype, Lay *l) {
+    if (!fft_has(g, dtype) || !make_layout(g, dtype, l)) return TNMF_E_UNSUPPORTED;
+    CHECK(ensure_ws(ctx, l->total));
+    ctx->last_path = "fft";
+    return TNMF_OK;
+}
+
+}  // namespace
+
+bool fft_has(const Geo &g, int dtype) {
+    if (g.Dy == 1 && g.Ay == 1) return false;   // 1-D signals stay on the direct kernels
+    return pick_len(g.Hy, dtype) != 0 && pick_len(g.Hx, dtype) != 0;
+}
+
+void fft_invalidate(tnmf_hip_ctx *ctx) { ctx->fft.T_valid = false; }
+
+void fft_release(tnmf_hip_ctx *ctx) {
+    if (ctx->fft.ws) (void)hipFree(ctx->fft.ws);
+    ctx->fft.ws = nullptr;
+    ctx->fft.ws_bytes = 0;
+    ctx->fft.T_valid = false;
+}
+
+int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
+    Lay l;
+    CHECK(prepare(ctx, g, dtype, &l));
+    CHECK(spectra_W(ctx, g, l, dtype, W, true, false, s));
+    CHECK(rows_of_H(ctx, g, l, dtype, H, s));
+    FftArgs a = base_args(g, l);
+    a.src0 = at(ctx, l.T);
+    a.src1 = at(ctx, l.SW);
+    a.dst0 = at(ctx, l.SR);
+    CHECK(l.colf(kFftContractR, dtype, &a, s));
+    FftArgs b = base_args(g, l);
+    b.src0 = at(ctx, l.SR);
+    b.dst0 = at(ctx, l.Ts);
+    b.planes = g.N * g.C;
+    b.rows = g.Dy;
+    b.yoff = g.Ay - 1;
+    CHECK(l.colf(kFftColsInv, dtype, &b, s));
+    FftArgs c = base_args(g, l);
+    c.src0 = at(ctx, l.Ts);
+    c.dst0 = R;
+    c.planes = g.N * g.C;
+    c.rows = g.Dy;
+    c.cols = g.Dx;
+    c.xoff = g.Ax - 1;
+    c.ld_dst = g.Dx;
+    c.ps_dst = (long)g.Dy * g.Dx;
+    return l.rowf(kFftRowsInv, dtype, &c, s);
+}
+
+namespace {
+
+// spectra of V and R, spectra of the flipped W, then neg/pos row spectra for every (sample, atom)
+int grad_H_rows(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, const void *R, const void *W,
+                hipStream_t s) {
+    CHECK(spectra_W(ctx, g, l, dtype, W, false, true, s));
+    CHECK(forward_planes(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SV), s));
+    CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
+    FftArgs a = base_args(g, l);
+    a.src0 = at(ctx, l.SV);
+    a.src1 = at(ctx, l.SR);
+    a.src2 = at(ctx, l.SWf);
+    a.dst0 = at(ctx, l.Tn);
+    a.dst1 = at(ctx, l.Tp);
+    a.n0 = 0;
+    a.planes = g.N;
+    return l.colf(kFftGradH, dtype, &a, s);
+}
+
+}  // namespace
+
+int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *neg,
+               void *pos, hipStream_t s) {
+    Lay l;
+    CHECK(prepare(ctx, g, dtype, &l));
+    CHECK(grad_H_rows(ctx, g, l, dtype, V, R, W, s));
+    FftArgs a = base_args(g, l);
+    a.src0 = at(ctx, l.Tn);
+    a.src1 = at(ctx, l.Tp);
+    a.dst0 = neg;
+    a.dst1 = pos;
+    a.planes = g.N * g.M;
+    a.rows = g.Hy;
+    a.cols = g.Hx;
+    a.xoff = 0;
+    a.ld_dst = g.Hx;
+    a.ps_dst = (long)g.Hy * g.Hx;
+    return l.rowf(kFftRowsInv2, dtype, &a, s);
+}
+
+int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *H,
+                 double reg, hipStream_t s) {
+    Lay l;
+    CHECK(prepare(ctx, g, dtype, &l));
+    CHECK(grad_H_rows(ctx, g, l, dtype, V, R, W, s));
+    ctx->fft.T_valid = false;
+    FftArgs a = base_args(g, l);
+    a.src0 = at(ctx, l.Tn);
+    a.src1 = at(ctx, l.Tp);
+    a.dst0 = H;
+    a.dst1 = at(ctx, l.T);
+    a.planes = g.N * g.M;
+    a.rows = g.Hy;
+    a.cols = g.Hx;
+    a.ld_dst = g.Hx;
+    a.ps_src = (long)g.Hy * g.Hx;
+    a.ps_dst = (long)g.Hy * l.KXP;
+    a.reg = reg;
+    CHECK(l.rowf(kFftRowsMu, dtype, &a, s));
+    T_mark(ctx, g, dtype, H);
+    return TNMF_OK;
+}
+
+int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *H, void *neg,
+               void *pos, hipStream_t s) {
+    Lay l;
+    CHECK(prepare(ctx, g, dtype, &l));
+    CHECK(rows_of_H(ctx, g, l, dtype, H, s));
+    CHECK(forward_planes(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SV), s));
+    CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
+    FftArgs a = base_args(g, l);
+    a.src0 = at(ctx, l.T);
+    a.src1 = at(ctx, l.SV);
+    a.src2 = at(ctx, l.SR);
+    a.dst0 = at(ctx, l.Gn);
+    a.dst1 = at(ctx, l.Gp);
+    a.ngroups = l.ngroups;
+    a.nper = l.nper;
+    CHECK(l.colf(kFftGradW, dtype, &a, s));
+    // fixed-order sum of the groups, scaled; both gradients side by side: [2][M*C][Ly][KXP]
+    const long count = (long)g.M * g.C * l.Ly * l.KXP;
+    const size_t sbytes = (size_t)count * l.csz;
+    const double scale = 1.0 / ((double)l.Ly * l.Lx);
+    for (int which = 0; which < 2; ++which) {
+        const char *parts = at(ctx, which ? l.Gp : l.Gn);
+        char *out = at(ctx, l.Gs) + which * sbytes;
+        if (dtype == 0)
+            hipLaunchKernelGGL(k_fft_sum_groups<float>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                               (const cplx<float> *)parts, (cplx<float> *)out, count, l.ngroups, scale);
+        else
+            hipLaunchKernelGGL(k_fft_sum_groups<double>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                               (const cplx<double> *)parts, (cplx<double> *)out, count, l.ngroups, scale);
+        TNMF_LAUNCH_CHECK();
+    }
+    const int planes = 2 * g.M * g.C;
+    FftArgs b = base_args(g, l);
+    b.src0 = at(ctx, l.Gs);
+    b.dst0 = at(ctx, l.TW);   // [2*M*C][Ay][KXP]
+    b.planes = planes;
+    b.rows = g.Ay;
+    b.yoff = 0;
+    CHECK(l.colf(kFftColsInv, dtype, &b, s));
+    FftArgs c = base_args(g, l);
+    c.src0 = at(ctx, l.TW);
+    c.dst0 = at(ctx, l.Wo);
+    c.planes = planes;
+    c.rows = g.Ay;
+    c.cols = g.Ax;
+    c.xoff = 0;
+    c.ld_dst = g.Ax;
+    c.ps_dst = (long)g.Ay * g.Ax;
+    CHECK(l.rowf(kFftRowsInv, dtype, &c, s));
+    const int per = g.M * g.C * g.Ay * g.Ax;
+    const char *wo = at(ctx, l.Wo);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(k_fft_flip_out<float>, dim3(cdiv(per, 256)), dim3(256), 0, s, (const float *)wo,
+                           (float *)neg, g.M * g.C, g.Ay, g.Ax);
+        hipLaunchKernelGGL(k_fft_flip_out<float>, dim3(cdiv(per, 256)), dim3(256), 0, s, (const float *)wo + per,
+                           (float *)pos, g.M * g.C, g.Ay, g.Ax);
+    } else {
+        hipLaunchKernelGGL(k_fft_flip_out<double>, dim3(cdiv(per, 256)), dim3(256), 0, s, (const double *)wo,
+                           (double *)neg, g.M * g.C, g.Ay, g.Ax);
+        hipLaunchKernelGGL(k_fft_flip_out<double>, dim3(cdiv(per, 256)), dim3(256), 0, s, (const double *)wo + per,
+                           (double *)pos, g.M * g.C, g.Ay, g.Ax);
+    }
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
