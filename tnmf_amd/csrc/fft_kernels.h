@@ -21,9 +21,9 @@ struct LenCfg {
     static constexpr int col_elems = L * kColTile / col_threads;   // tile elements per thread
     static constexpr int row_pairs = L > 288 ? 8 : 16;
     static constexpr int row_threads = 256;
+    static constexpr int mu_pairs = L > 288 ? 4 : 8;   // the fused update kernel keeps its tile small: more blocks per CU
     // channels per pass of the contraction kernels (accumulators live in registers)
-    static constexpr int cg_R = 4;
-    static constexpr int cg_W = col_elems <= 9 ? 4 : 2;
+    static constexpr int cg_W = 2;   // the W-gradient kernel carries two accumulator sets per channel
 };
 
 template <typename T, int L>
@@ -38,20 +38,26 @@ __device__ __forceinline__ void make_twiddles(cplx<T> *tw, int tid, int nt) {
 // all NB sequences of the tile, forward; the caller has synchronised the tile, the function ends synchronised
 template <typename T, typename P, int NB, int BS, int NT>
 __device__ __forceinline__ void tile_fwd(cplx<T> *x, const cplx<T> *tw, int tid) {
+#pragma unroll 1
     for (int t = tid; t < NB * P::tasks1; t += NT) P::template fwd1<BS>(x + (t % NB), tw, t / NB);
     __syncthreads();
+#pragma unroll 1
     for (int t = tid; t < NB * P::tasks2; t += NT) P::template fwd2<BS>(x + (t % NB), tw, t / NB);
     __syncthreads();
+#pragma unroll 1
     for (int t = tid; t < NB * P::tasks3; t += NT) P::template fwd3<BS>(x + (t % NB), t / NB);
     __syncthreads();
 }
 
 template <typename T, typename P, int NB, int BS, int NT>
 __device__ __forceinline__ void tile_inv(cplx<T> *x, const cplx<T> *tw, int tid) {
+#pragma unroll 1
     for (int t = tid; t < NB * P::tasks3; t += NT) P::template inv3<BS>(x + (t % NB), t / NB);
     __syncthreads();
+#pragma unroll 1
     for (int t = tid; t < NB * P::tasks2; t += NT) P::template inv2<BS>(x + (t % NB), tw, t / NB);
     __syncthreads();
+#pragma unroll 1
     for (int t = tid; t < NB * P::tasks1; t += NT) P::template inv1<BS>(x + (t % NB), tw, t / NB);
     __syncthreads();
 }
@@ -173,6 +179,97 @@ __global__ __launch_bounds__(NT) void k_fft_rows_inv(FftArgs a) {
     }
 }
 
+// kFftRowsMu: src0 = neg, src1 = pos row spectra; dst0 = H real (in/out; ps_src / ld_dst / cols describe it);
+//   H = (H*neg)/(pos+reg)  (TransformInvariantNMF.py:232-235), then dst1 = row spectra of the new H.
+// One LDS tile is used three times (neg, pos, new H): the neg values, the pos spectra and the H values a thread needs
+// are staged in registers, loaded before the first transform so that their latency hides behind it.
+template <typename T, int L, int NB, int NT>
+__global__ __launch_bounds__(NT) void k_fft_rows_mu(FftArgs a) {
+    using P = FftPlanFor<T, L>;
+    constexpr int BS = NB + 1, KX = L / 2 + 1;
+    constexpr int RE = (2 * NB * L + NT - 1) / NT;     // real tile elements per thread
+    constexpr int SE = (NB * KX + NT - 1) / NT;         // (pair, kx) spectrum elements per thread
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
+    cplx<T> *tw = x + L * BS;
+    const int tid = threadIdx.x, y0 = blockIdx.x * 2 * NB;
+    const long plane = blockIdx.y;
+    make_twiddles<T, L>(tw, tid, NT);
+    const long tin = plane * ((long)a.rows * a.KXP);
+    const cplx<T> *sp = static_cast<const cplx<T> *>(a.src1) + tin;
+    T *Hp = static_cast<T *>(a.dst0) + plane * a.ps_src;
+    // unconditional loads on clamped addresses (masked when used)
+    cplx<T> pa[SE], pb[SE];
+#pragma unroll
+    for (int e = 0; e < SE; ++e) {
+        int idx = tid + e * NT;
+        idx = idx < NB * KX ? idx : NB * KX - 1;
+        const int pr = idx / KX, k = idx - pr * KX;
+        const int ya = min(y0 + 2 * pr, a.rows - 1), yb = min(y0 + 2 * pr + 1, a.rows - 1);
+        pa[e] = sp[(long)ya * a.KXP + k];
+        pb[e] = sp[(long)yb * a.KXP + k];
+    }
+    T hv[RE];
+#pragma unroll
+    for (int e = 0; e < RE; ++e) {
+        int idx = tid + e * NT;
+        idx = idx < 2 * NB * L ? idx : 2 * NB * L - 1;
+        const int r = idx / L, xx = idx - r * L;
+        hv[e] = Hp[(long)min(y0 + r, a.rows - 1) * a.ld_dst + min(xx, a.cols - 1)];
+    }
+    load_rows_merge<T, P, NB, BS, NT>(x, static_cast<const cplx<T> *>(a.src0) + tin, y0, a.rows, a.KXP, tid);
+    __syncthreads();
+    tile_inv<T, P, NB, BS, NT>(x, tw, tid);
+    T *xr = reinterpret_cast<T *>(x);
+    T ng[RE];
+#pragma unroll
+    for (int e = 0; e < RE; ++e) {
+        int idx = tid + e * NT;
+        idx = idx < 2 * NB * L ? idx : 2 * NB * L - 1;
+        const int r = idx / L, xx = idx - r * L;
+        ng[e] = xr[(xx * BS + (r >> 1)) * 2 + (r & 1)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < SE; ++e) {
+        const int idx = tid + e * NT;
+        if (idx < NB * KX) {
+            const int pr = idx / KX, k = idx - pr * KX, ya = y0 + 2 * pr;
+            cplx<T> A = pa[e], B = pb[e];
+            if (ya >= a.rows) A = {0, 0};
+            if (ya + 1 >= a.rows) B = {0, 0};
+            if (k == 0 || 2 * k == L) {
+                x[P::pos_of_k(k) * BS + pr] = {A.x, B.x};
+            } else {
+                cplx<T> zk, zlk;
+                merge_pair(A, B, zk, zlk);
+                x[P::pos_of_k(k) * BS + pr] = zk;
+                x[P::pos_of_k(L - k) * BS + pr] = zlk;
+            }
+        }
+    }
+    __syncthreads();
+    tile_inv<T, P, NB, BS, NT>(x, tw, tid);
+    const T reg = (T)a.reg;
+#pragma unroll
+    for (int e = 0; e < RE; ++e) {
+        const int idx = tid + e * NT;
+        if (idx < 2 * NB * L) {
+            const int r = idx / L, xx = idx - r * L, y = y0 + r;
+            const int off = (xx * BS + (r >> 1)) * 2 + (r & 1);
+            T hn = 0;
+            if (y < a.rows && xx < a.cols) {
+                hn = (hv[e] * ng[e]) / (xr[off] + reg);
+                Hp[(long)y * a.ld_dst + xx] = hn;
+            }
+            xr[off] = hn;
+        }
+    }
+    __syncthreads();
+    tile_fwd<T, P, NB, BS, NT>(x, tw, tid);
+    store_rows_split<T, P, NB, BS, NT>(x, static_cast<cplx<T> *>(a.dst1) + plane * a.ps_dst, y0, a.rows, a.KXP, tid);
+}
+
 // ---- column kernels ---------------------------------------------------------------------------------------------
 
 // tile <- rows [0, rows) x columns [kx0, kx0+16) of one plane of row spectra; zero elsewhere
@@ -233,9 +330,41 @@ __global__ __launch_bounds__(NT) void k_fft_cols_inv(FftArgs a) {
                                a.KXP, a.KX, kx0, tid);
 }
 
+// Register staging of a column tile: the loads are unconditional on clamped addresses (hipcc keeps them in flight
+// across the transform of the previous tile); what lies outside the data is zeroed when the tile is committed to LDS.
+// Addresses are a uniform plane base plus per-thread 32-bit byte offsets that do not change from tile to tile.
+// per-thread part of the element offsets of a column tile: element e of the thread sits at row (tid>>4) + e*NT/16
+struct ColLane {
+    int y0, kxc;   // first row of the thread, clamped kx
+};
+template <int NT>
+__device__ __forceinline__ ColLane col_lane(int KX, int kx0, int tid) {
+    return {tid >> 4, min(kx0 + (tid & 15), KX - 1)};
+}
+
+// pre[e] <- base[min(row_e, rows-1)][kx]  (base: one plane, uniform)
+template <typename T, int L, int NT>
+__device__ __forceinline__ void fetch_col(cplx<T> *pre, const cplx<T> *base, ColLane ln, int rows, int KXP) {
+    constexpr int E = L * kColTile / NT;
+#pragma unroll
+    for (int e = 0; e < E; ++e) pre[e] = base[(unsigned)(min(ln.y0 + e * (NT / 16), rows - 1) * KXP + ln.kxc)];
+}
+
+template <typename T, int L, int NT>
+__device__ __forceinline__ void commit_col_tile(cplx<T> *x, const cplx<T> *pre, int rows, int KX, int kx0, int tid) {
+    constexpr int E = L * kColTile / NT;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = tid + e * NT, y = idx >> 4, col = idx & 15;
+        cplx<T> v = pre[e];
+        if (y >= rows || kx0 + col >= KX) v = {0, 0};
+        x[y * kColBS + col] = v;
+    }
+}
+
 // kFftContractR: R^[n,c,f] = sum_m H^[n,m,f] W^[m,c,f]   (reconstruct, NumPy.py:122-132 in the frequency domain)
 //   src0 = row spectra of H [N*M][Hy][KXP], src1 = W spectra [M*C][L][KXP], dst0 = R spectra [N*C][L][KXP]
-//   grid (N, tiles, channel groups of CG)
+//   grid (N, tiles, channel groups of CG).  The next atom's tile is fetched while the current one is transformed.
 template <typename T, int L, int NT, int CG>
 __global__ __launch_bounds__(NT) void k_fft_contract_R(FftArgs a) {
     using P = FftPlanFor<T, L>;
@@ -248,24 +377,26 @@ __global__ __launch_bounds__(NT) void k_fft_contract_R(FftArgs a) {
     const cplx<T> *Tsrc = static_cast<const cplx<T> *>(a.src0);
     const cplx<T> *SW = static_cast<const cplx<T> *>(a.src1);
     const long tplane = (long)a.Hy * a.KXP, splane = (long)L * a.KXP;
-    cplx<T> acc[CG][E];
+    cplx<T> acc[CG][E], pre[E];
+    const ColLane ln = col_lane<NT>(a.KX, kx0, tid);
 #pragma unroll
     for (int cc = 0; cc < CG; ++cc)
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[cc][e] = {0, 0};
+    fetch_col<T, L, NT>(pre, Tsrc + (long)n * a.M * tplane, ln, a.Hy, a.KXP);
     for (int m = 0; m < a.M; ++m) {
-        load_col_tile<T, L, NT>(x, Tsrc + ((long)n * a.M + m) * tplane, a.Hy, a.KXP, a.KX, kx0, tid);
+        commit_col_tile<T, L, NT>(x, pre, a.Hy, a.KX, kx0, tid);
         __syncthreads();
+        fetch_col<T, L, NT>(pre, Tsrc + ((long)n * a.M + min(m + 1, a.M - 1)) * tplane, ln, a.Hy, a.KXP);
         tile_fwd<T, P, kColTile, kColBS, NT>(x, tw, tid);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15, kx = kx0 + col;
+            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15;
             const cplx<T> h = x[pos * kColBS + col];
-            if (kx < a.KX) {
 #pragma unroll
-                for (int cc = 0; cc < CG; ++cc)
-                    if (c0 + cc < a.C)
-                        cfma(acc[cc][e], h, SW[((long)m * a.C + c0 + cc) * splane + (long)pos * a.KXP + kx]);
+            for (int cc = 0; cc < CG; ++cc) {
+                const cplx<T> *b = SW + ((long)m * a.C + min(c0 + cc, a.C - 1)) * splane;
+                cfma(acc[cc][e], h, b[(unsigned)(pos * a.KXP + ln.kxc)]);
             }
         }
         __syncthreads();
@@ -285,52 +416,52 @@ __global__ __launch_bounds__(NT) void k_fft_contract_R(FftArgs a) {
 // kFftGradH: neg^[n,m,f] = sum_c V^[n,c,f] Wf^[m,c,f], pos^ likewise with R^ (NumPy.py:93-120 in the frequency domain;
 //   Wf = W flipped along the shift axes), inverse transform along y, rows [0, Hy) kept.
 //   src0 = V spectra [N*C][L][KXP], src1 = R spectra, src2 = Wf spectra [M*C][L][KXP];
-//   dst0, dst1 = row spectra of neg, pos [(n-n0)*M+m][Hy][KXP];  grid (samples of the window, tiles)
-template <typename T, int L, int NT>
+//   dst0, dst1 = row spectra of neg, pos [(n-n0)*M+m][Hy][KXP];  grid (samples of the window, tiles, 2): blockIdx.z
+//   selects neg (from V^) or pos (from R^), so that a block keeps one spectrum of its sample in registers.
+//   CH = 1..4: that many channels held in registers (CH == C); CH = 0: any C, reloaded per atom.
+template <typename T, int L, int NT, int CH>
 __global__ __launch_bounds__(NT) void k_fft_grad_H(FftArgs a) {
     using P = FftPlanFor<T, L>;
-    constexpr int E = L * kColTile / NT;
+    constexpr int E = L * kColTile / NT, CR = CH > 0 ? CH : 1;
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
     cplx<T> *tw = x + L * kColBS;
     const int tid = threadIdx.x, nl = blockIdx.x, n = a.n0 + nl, kx0 = blockIdx.y * kColTile;
     make_twiddles<T, L>(tw, tid, NT);
-    const cplx<T> *SV = static_cast<const cplx<T> *>(a.src0);
-    const cplx<T> *SR = static_cast<const cplx<T> *>(a.src1);
+    const cplx<T> *S = static_cast<const cplx<T> *>(blockIdx.z ? a.src1 : a.src0);
     const cplx<T> *SWf = static_cast<const cplx<T> *>(a.src2);
-    cplx<T> *Tn = static_cast<cplx<T> *>(a.dst0);
-    cplx<T> *Tp = static_cast<cplx<T> *>(a.dst1);
+    cplx<T> *Tout = static_cast<cplx<T> *>(blockIdx.z ? a.dst1 : a.dst0);
     const long tplane = (long)a.Hy * a.KXP, splane = (long)L * a.KXP;
+    const ColLane ln = col_lane<NT>(a.KX, kx0, tid);
+    cplx<T> sv[CR][E], wf[CH == 1 ? E : 1];
+    if (CH > 0) {
+#pragma unroll
+        for (int c = 0; c < CR; ++c) fetch_col<T, L, NT>(sv[c], S + ((long)n * a.C + c) * splane, ln, L, a.KXP);
+    }
+    if (CH == 1) fetch_col<T, L, NT>(wf, SWf, ln, L, a.KXP);
     __syncthreads();
     for (int m = 0; m < a.M; ++m) {
-        cplx<T> ps[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15, kx = kx0 + col;
-            cplx<T> ng = {0, 0};
-            ps[e] = {0, 0};
-            if (kx < a.KX) {
-                for (int c = 0; c < a.C; ++c) {
-                    const long o = (long)pos * a.KXP + kx;
-                    const cplx<T> w = SWf[((long)m * a.C + c) * splane + o];
-                    cfma(ng, SV[((long)n * a.C + c) * splane + o], w);
-                    cfma(ps[e], SR[((long)n * a.C + c) * splane + o], w);
-                }
-            }
-            x[pos * kColBS + col] = ng;
-        }
-        __syncthreads();
-        tile_inv<T, P, kColTile, kColBS, NT>(x, tw, tid);
-        store_col_tile_rows<T, NT>(x, Tn + ((long)nl * a.M + m) * tplane, a.Hy, 0, a.KXP, a.KX, kx0, tid);
-        __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15;
-            x[pos * kColBS + col] = ps[e];
+            cplx<T> g = {0, 0};
+            if (CH == 1) {
+                cfma(g, sv[0][e], wf[e]);
+            } else if (CH > 1) {
+#pragma unroll
+                for (int c = 0; c < CR; ++c)
+                    cfma(g, sv[c][e], (SWf + ((long)m * a.C + c) * splane)[(unsigned)(pos * a.KXP + ln.kxc)]);
+            } else {
+                for (int c = 0; c < a.C; ++c)
+                    cfma(g, (S + ((long)n * a.C + c) * splane)[(unsigned)(pos * a.KXP + ln.kxc)],
+                         (SWf + ((long)m * a.C + c) * splane)[(unsigned)(pos * a.KXP + ln.kxc)]);
+            }
+            x[pos * kColBS + col] = g;
         }
         __syncthreads();
+        if (CH == 1) fetch_col<T, L, NT>(wf, SWf + (long)min(m + 1, a.M - 1) * splane, ln, L, a.KXP);
         tile_inv<T, P, kColTile, kColBS, NT>(x, tw, tid);
-        store_col_tile_rows<T, NT>(x, Tp + ((long)nl * a.M + m) * tplane, a.Hy, 0, a.KXP, a.KX, kx0, tid);
+        store_col_tile_rows<T, NT>(x, Tout + ((long)nl * a.M + m) * tplane, a.Hy, 0, a.KXP, a.KX, kx0, tid);
         __syncthreads();
     }
 }
@@ -352,7 +483,7 @@ __global__ __launch_bounds__(NT) void k_fft_grad_W(FftArgs a) {
     const cplx<T> *SV = static_cast<const cplx<T> *>(a.src1);
     const cplx<T> *SR = static_cast<const cplx<T> *>(a.src2);
     const long tplane = (long)a.Hy * a.KXP, splane = (long)L * a.KXP;
-    cplx<T> an[CG][E], ap[CG][E];
+    cplx<T> an[CG][E], ap[CG][E], pre[E];
 #pragma unroll
     for (int cc = 0; cc < CG; ++cc)
 #pragma unroll
@@ -361,22 +492,33 @@ __global__ __launch_bounds__(NT) void k_fft_grad_W(FftArgs a) {
             ap[cc][e] = {0, 0};
         }
     const int nbeg = grp * a.nper, nend = min(a.N, nbeg + a.nper);
+    const ColLane ln = col_lane<NT>(a.KX, kx0, tid);
+    if (nbeg < nend) fetch_col<T, L, NT>(pre, Tsrc + ((long)nbeg * a.M + m) * tplane, ln, a.Hy, a.KXP);
     for (int n = nbeg; n < nend; ++n) {
-        load_col_tile<T, L, NT>(x, Tsrc + ((long)n * a.M + m) * tplane, a.Hy, a.KXP, a.KX, kx0, tid);
+        commit_col_tile<T, L, NT>(x, pre, a.Hy, a.KX, kx0, tid);
         __syncthreads();
+        cplx<T> v[CG == 1 ? E : 1], r[CG == 1 ? E : 1];
+        if (CG == 1) {
+            fetch_col<T, L, NT>(v, SV + ((long)n * a.C + c0) * splane, ln, L, a.KXP);
+            fetch_col<T, L, NT>(r, SR + ((long)n * a.C + c0) * splane, ln, L, a.KXP);
+        }
+        fetch_col<T, L, NT>(pre, Tsrc + ((long)min(n + 1, nend - 1) * a.M + m) * tplane, ln, a.Hy, a.KXP);
         tile_fwd<T, P, kColTile, kColBS, NT>(x, tw, tid);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15, kx = kx0 + col;
+            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15;
             const cplx<T> h = x[pos * kColBS + col];
-            if (kx < a.KX) {
+            if (CG == 1) {
+                cfmac(an[0][e], h, v[e]);
+                cfmac(ap[0][e], h, r[e]);
+            } else {
 #pragma unroll
-                for (int cc = 0; cc < CG; ++cc)
-                    if (c0 + cc < a.C) {
-                        const long o = ((long)n * a.C + c0 + cc) * splane + (long)pos * a.KXP + kx;
-                        cfmac(an[cc][e], h, SV[o]);
-                        cfmac(ap[cc][e], h, SR[o]);
-                    }
+                for (int cc = 0; cc < CG; ++cc) {
+                    const long pl = ((long)n * a.C + min(c0 + cc, a.C - 1)) * splane;
+                    const unsigned o = (unsigned)(pos * a.KXP + ln.kxc);
+                    cfmac(an[cc][e], h, (SV + pl)[o]);
+                    cfmac(ap[cc][e], h, (SR + pl)[o]);
+                }
             }
         }
         __syncthreads();
@@ -433,18 +575,31 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
         case kFftRowsFwd: TNMF_FFT_LAUNCH((k_fft_rows_fwd<T, L, NB, NTR>), rgrid, NTR, row_tile + tw_bytes);
         case kFftRowsInv: TNMF_FFT_LAUNCH((k_fft_rows_inv<T, L, NB, NTR, 0>), rgrid, NTR, row_tile + tw_bytes);
         case kFftRowsInv2: TNMF_FFT_LAUNCH((k_fft_rows_inv<T, L, NB, NTR, 1>), rgrid, NTR, 2 * row_tile + tw_bytes);
-        case kFftRowsMu: TNMF_FFT_LAUNCH((k_fft_rows_inv<T, L, NB, NTR, 2>), rgrid, NTR, 2 * row_tile + tw_bytes);
+        case kFftRowsMu: {
+            constexpr int NBM = Cfg::mu_pairs;
+            const dim3 mgrid((unsigned)cdiv(a->rows, 2 * NBM), (unsigned)a->planes);
+            TNMF_FFT_LAUNCH((k_fft_rows_mu<T, L, NBM, NTR>), mgrid, NTR, (size_t)L * (NBM + 1) * sizeof(cplx<T>) + tw_bytes);
+        }
         case kFftColsFwd:
             TNMF_FFT_LAUNCH((k_fft_cols_fwd<T, L, NTC>), dim3(tiles, (unsigned)a->planes), NTC, col_lds);
         case kFftColsInv:
             TNMF_FFT_LAUNCH((k_fft_cols_inv<T, L, NTC>), dim3(tiles, (unsigned)a->planes), NTC, col_lds);
-        case kFftContractR:
-            if (a->C == 1)
-                TNMF_FFT_LAUNCH((k_fft_contract_R<T, L, NTC, 1>), dim3((unsigned)a->N, tiles, 1), NTC, col_lds);
-            TNMF_FFT_LAUNCH((k_fft_contract_R<T, L, NTC, Cfg::cg_R>),
-                            dim3((unsigned)a->N, tiles, (unsigned)cdiv(a->C, Cfg::cg_R)), NTC, col_lds);
-        case kFftGradH:
-            TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC>), dim3((unsigned)a->planes, tiles), NTC, col_lds);
+        case kFftContractR: {
+            const int cg = a->C <= 3 ? a->C : 4;
+            const dim3 grid((unsigned)a->N, tiles, (unsigned)cdiv(a->C, cg));
+            if (cg == 1) TNMF_FFT_LAUNCH((k_fft_contract_R<T, L, NTC, 1>), grid, NTC, col_lds);
+            if (cg == 2) TNMF_FFT_LAUNCH((k_fft_contract_R<T, L, NTC, 2>), grid, NTC, col_lds);
+            if (cg == 3) TNMF_FFT_LAUNCH((k_fft_contract_R<T, L, NTC, 3>), grid, NTC, col_lds);
+            TNMF_FFT_LAUNCH((k_fft_contract_R<T, L, NTC, 4>), grid, NTC, col_lds);
+        }
+        case kFftGradH: {
+            const dim3 grid((unsigned)a->planes, tiles, 2);
+            if (a->C == 1) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 1>), grid, NTC, col_lds);
+            if (a->C == 2) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 2>), grid, NTC, col_lds);
+            if (a->C == 3) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 3>), grid, NTC, col_lds);
+            if (a->C == 4) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 4>), grid, NTC, col_lds);
+            TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 0>), grid, NTC, col_lds);
+        }
         case kFftGradW:
             if (a->C == 1)
                 TNMF_FFT_LAUNCH((k_fft_grad_W<T, L, NTC, 1>), dim3((unsigned)a->M, tiles, (unsigned)a->ngroups), NTC,
