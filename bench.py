@@ -146,6 +146,7 @@ def main():
     ap.add_argument('--samples', type=int, default=None, help='override samples per GPU (debug)')
     ap.add_argument('--path', default='auto', choices=['auto', 'generic', 'mfma', 'fft'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fft-variant', action='store_true', help='skip the second timed leg on the FFT kernel family')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
 
@@ -224,6 +225,39 @@ def main():
     elapsed = float(t.item())
     energy = nmf._energy_function()     # collective when sharded; outside the timed region
 
+    # Second leg (single GPU only): the same iterations from the same start on the FFT kernel family -- the
+    # frequency-domain formulation of the same update (BASELINE.json configs[4]: "FFT-vs-direct crossover").
+    fft_variant = None
+    if world == 1 and args.path != 'fft' and not args.no_fft_variant and k == 2:
+        np.random.seed(42)
+        torch.cuda.manual_seed(4242 + rank)
+        nmf2 = TransformInvariantNMF(n_atoms=cfg['M'], atom_shape=tuple(cfg['A']), backend='hip', device=device,
+                                     path='fft', init='device')
+        nmf2._initialize_matrices(V, keep_W=False)
+        for _ in range(args.warmup):
+            nmf2._update_H()
+            nmf2._update_W()
+        torch.cuda.synchronize(device)
+        nmf2._backend.start_timeline()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            nmf2._update_H()
+            nmf2._update_W()
+        torch.cuda.synchronize(device)
+        el2 = time.perf_counter() - t1
+        spans2 = nmf2._backend.stop_timeline()
+        Wd, Wf = nmf.W, nmf2.W
+        fft_variant = {
+            'value': args.steps / el2, 'unit': 'MU-iterations/sec', 'ms_per_step': el2 / args.steps * 1e3,
+            'kernel_path': nmf2._backend.last_path,
+            'what': "same data, same start, same iteration count on path='fft' (own LDS transforms, fused contractions)",
+            'kernels_ms': {name: float(np.mean(ms)) for name, ms in spans2.items()},
+            'W_max_rel_diff_vs_direct': float(np.abs(Wf - Wd).max() / np.abs(Wd).max()),
+            'energy_after_run': nmf2._energy_function(),
+            'speedup_over_direct': (args.steps / el2) / (world * args.steps / elapsed),
+        }
+        del nmf2
+
     if rank == 0:
         F = conv_flops(cfg, n_local)
         flops_per_launch = {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}
@@ -262,6 +296,8 @@ def main():
                 'flops_per_launch': flops_per_launch[dom], 'avg_launch_ms': kernels[dom]['avg_ms'],
             },
         }
+        if fft_variant is not None:
+            line['fft_variant'] = fft_variant
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_budget)
             line['cpu_baseline']['gpu_over_cpu'] = line['value'] / line['cpu_baseline']['value']
