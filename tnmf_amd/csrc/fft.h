@@ -20,6 +20,7 @@ struct FftArgs {
     int yoff, xoff;          // crop offsets of the inverse kernels
     int N, M, C, Hy;         // contraction kernels
     int n0, ngroups, nper;   // sample window / split of the sample sum
+    int mgroups, mper;       // split of the atom loop of the H-gradient kernel over blocks
     double reg;              // eps (+ sparsity) of the fused update
 };
 

@@ -40,7 +40,7 @@ fft_run_fn lookup(int L) {
 
 // workspace layout, in bytes
 struct Lay {
-    int Ly, Lx, KX, KXP, ngroups, nper;
+    int Ly, Lx, KX, KXP, ngroups, nper, chunk, mgroups, mper;
     fft_run_fn rowf, colf;
     size_t csz;  // bytes of one complex element
     size_t T, Tn, Tp, SV, SR, Ts, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total;
@@ -64,6 +64,23 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
     l->ngroups = cdiv(g.N > 0 ? g.N : 1, l->nper);
     const size_t c = l->csz, kxp = (size_t)l->KXP;
     const size_t nT = (size_t)g.N * g.M * g.Hy * kxp * c;
+    // H half step in windows of `chunk` samples, which bounds the neg/pos row spectra (written by the column kernel, read
+    // back by the row kernel right after) to 8 GB.  Measured at config 3: windows small enough for the 256 MiB Infinity
+    // Cache are slower (launch tails: 24 MB 11.3 ms, 96 MB 7.3 ms, unwindowed 6.1 ms), so the window is as large as
+    // the budget allows.
+    const size_t per_sample = (size_t)2 * g.M * g.Hy * kxp * c;
+    size_t budget = (size_t)8 << 30;
+    if (const char *e = getenv("TNMF_FFT_WINDOW_MB")) budget = (size_t)atol(e) << 20;
+    long chunk = (long)(budget / per_sample);
+    if (chunk < 1) chunk = 1;
+    if (chunk > g.N) chunk = g.N > 0 ? g.N : 1;
+    l->chunk = (int)chunk;
+    int mg = cdiv(1024, l->chunk * tiles * 2);
+    if (mg > g.M) mg = g.M;
+    if (mg < 1) mg = 1;
+    l->mper = cdiv(g.M, mg);
+    l->mgroups = cdiv(g.M, l->mper);
+    const size_t nTc = (size_t)l->chunk * g.M * g.Hy * kxp * c;
     const size_t nS = (size_t)g.N * g.C * l->Ly * kxp * c;
     const size_t nSW = (size_t)g.M * g.C * l->Ly * kxp * c;
     size_t o = 0;
@@ -73,8 +90,8 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
         return at;
     };
     l->T = take(nT);
-    l->Tn = take(nT);
-    l->Tp = take(nT);
+    l->Tn = take(nTc);
+    l->Tp = take(nTc);
     l->SV = take(nS);
     l->SR = take(nS);
     l->Ts = take((size_t)g.N * g.C * g.Dy * kxp * c);
@@ -288,20 +305,26 @@ int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, c
 
 namespace {
 
-// spectra of V and R, spectra of the flipped W, then neg/pos row spectra for every (sample, atom)
-int grad_H_rows(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, const void *R, const void *W,
-                hipStream_t s) {
+// spectra of V and R and of the flipped W: what the H-gradient column kernel contracts
+int grad_H_spectra(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, const void *R,
+                   const void *W, hipStream_t s) {
     CHECK(spectra_W(ctx, g, l, dtype, W, false, true, s));
     CHECK(forward_planes(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SV), s));
-    CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
+    return forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s);
+}
+
+// neg/pos row spectra of the samples [n0, n0+cnt) into the window buffers
+int grad_H_window(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, int n0, int cnt, hipStream_t s) {
     FftArgs a = base_args(g, l);
     a.src0 = at(ctx, l.SV);
     a.src1 = at(ctx, l.SR);
     a.src2 = at(ctx, l.SWf);
     a.dst0 = at(ctx, l.Tn);
     a.dst1 = at(ctx, l.Tp);
-    a.n0 = 0;
-    a.planes = g.N;
+    a.n0 = n0;
+    a.planes = cnt;
+    a.mgroups = l.mgroups;
+    a.mper = l.mper;
     return l.colf(kFftGradH, dtype, &a, s);
 }
 
@@ -311,40 +334,51 @@ int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
                void *pos, hipStream_t s) {
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l));
-    CHECK(grad_H_rows(ctx, g, l, dtype, V, R, W, s));
-    FftArgs a = base_args(g, l);
-    a.src0 = at(ctx, l.Tn);
-    a.src1 = at(ctx, l.Tp);
-    a.dst0 = neg;
-    a.dst1 = pos;
-    a.planes = g.N * g.M;
-    a.rows = g.Hy;
-    a.cols = g.Hx;
-    a.xoff = 0;
-    a.ld_dst = g.Hx;
-    a.ps_dst = (long)g.Hy * g.Hx;
-    return l.rowf(kFftRowsInv2, dtype, &a, s);
+    CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));
+    const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hx;
+    for (int n0 = 0; n0 < g.N; n0 += l.chunk) {
+        const int cnt = g.N - n0 < l.chunk ? g.N - n0 : l.chunk;
+        CHECK(grad_H_window(ctx, g, l, dtype, n0, cnt, s));
+        FftArgs a = base_args(g, l);
+        a.src0 = at(ctx, l.Tn);
+        a.src1 = at(ctx, l.Tp);
+        a.dst0 = static_cast<char *>(neg) + (size_t)n0 * hplane * esz;
+        a.dst1 = static_cast<char *>(pos) + (size_t)n0 * hplane * esz;
+        a.planes = cnt * g.M;
+        a.rows = g.Hy;
+        a.cols = g.Hx;
+        a.xoff = 0;
+        a.ld_dst = g.Hx;
+        a.ps_dst = (long)g.Hy * g.Hx;
+        CHECK(l.rowf(kFftRowsInv2, dtype, &a, s));
+    }
+    return TNMF_OK;
 }
 
 int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *H,
                  double reg, hipStream_t s) {
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l));
-    CHECK(grad_H_rows(ctx, g, l, dtype, V, R, W, s));
+    CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));
     ctx->fft.T_valid = false;
-    FftArgs a = base_args(g, l);
-    a.src0 = at(ctx, l.Tn);
-    a.src1 = at(ctx, l.Tp);
-    a.dst0 = H;
-    a.dst1 = at(ctx, l.T);
-    a.planes = g.N * g.M;
-    a.rows = g.Hy;
-    a.cols = g.Hx;
-    a.ld_dst = g.Hx;
-    a.ps_src = (long)g.Hy * g.Hx;
-    a.ps_dst = (long)g.Hy * l.KXP;
-    a.reg = reg;
-    CHECK(l.rowf(kFftRowsMu, dtype, &a, s));
+    const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hx, tplane = (size_t)g.M * g.Hy * l.KXP;
+    for (int n0 = 0; n0 < g.N; n0 += l.chunk) {
+        const int cnt = g.N - n0 < l.chunk ? g.N - n0 : l.chunk;
+        CHECK(grad_H_window(ctx, g, l, dtype, n0, cnt, s));
+        FftArgs a = base_args(g, l);
+        a.src0 = at(ctx, l.Tn);
+        a.src1 = at(ctx, l.Tp);
+        a.dst0 = static_cast<char *>(H) + (size_t)n0 * hplane * esz;
+        a.dst1 = at(ctx, l.T) + (size_t)n0 * tplane * l.csz;
+        a.planes = cnt * g.M;
+        a.rows = g.Hy;
+        a.cols = g.Hx;
+        a.ld_dst = g.Hx;
+        a.ps_src = (long)g.Hy * g.Hx;
+        a.ps_dst = (long)g.Hy * l.KXP;
+        a.reg = reg;
+        CHECK(l.rowf(kFftRowsMu, dtype, &a, s));
+    }
     T_mark(ctx, g, dtype, H);
     return TNMF_OK;
 }

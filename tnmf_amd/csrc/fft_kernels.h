@@ -416,8 +416,9 @@ __global__ __launch_bounds__(NT) void k_fft_contract_R(FftArgs a) {
 // kFftGradH: neg^[n,m,f] = sum_c V^[n,c,f] Wf^[m,c,f], pos^ likewise with R^ (NumPy.py:93-120 in the frequency domain;
 //   Wf = W flipped along the shift axes), inverse transform along y, rows [0, Hy) kept.
 //   src0 = V spectra [N*C][L][KXP], src1 = R spectra, src2 = Wf spectra [M*C][L][KXP];
-//   dst0, dst1 = row spectra of neg, pos [(n-n0)*M+m][Hy][KXP];  grid (samples of the window, tiles, 2): blockIdx.z
-//   selects neg (from V^) or pos (from R^), so that a block keeps one spectrum of its sample in registers.
+//   dst0, dst1 = row spectra of neg, pos [(n-n0)*M+m][Hy][KXP];  grid (samples of the window, tiles, 2 * atom groups):
+//   blockIdx.z selects neg (from V^) or pos (from R^), so that a block keeps one spectrum of its sample in registers,
+//   and a group of mper atoms (the window is a few samples only, see fft.hip: the atom groups fill the chip).
 //   CH = 1..4: that many channels held in registers (CH == C); CH = 0: any C, reloaded per atom.
 template <typename T, int L, int NT, int CH>
 __global__ __launch_bounds__(NT) void k_fft_grad_H(FftArgs a) {
@@ -428,9 +429,10 @@ __global__ __launch_bounds__(NT) void k_fft_grad_H(FftArgs a) {
     cplx<T> *tw = x + L * kColBS;
     const int tid = threadIdx.x, nl = blockIdx.x, n = a.n0 + nl, kx0 = blockIdx.y * kColTile;
     make_twiddles<T, L>(tw, tid, NT);
-    const cplx<T> *S = static_cast<const cplx<T> *>(blockIdx.z ? a.src1 : a.src0);
+    const int which = blockIdx.z & 1, mbeg = (blockIdx.z >> 1) * a.mper, mend = min(a.M, mbeg + a.mper);
+    const cplx<T> *S = static_cast<const cplx<T> *>(which ? a.src1 : a.src0);
     const cplx<T> *SWf = static_cast<const cplx<T> *>(a.src2);
-    cplx<T> *Tout = static_cast<cplx<T> *>(blockIdx.z ? a.dst1 : a.dst0);
+    cplx<T> *Tout = static_cast<cplx<T> *>(which ? a.dst1 : a.dst0);
     const long tplane = (long)a.Hy * a.KXP, splane = (long)L * a.KXP;
     const ColLane ln = col_lane<NT>(a.KX, kx0, tid);
     cplx<T> sv[CR][E], wf[CH == 1 ? E : 1];
@@ -438,9 +440,9 @@ __global__ __launch_bounds__(NT) void k_fft_grad_H(FftArgs a) {
 #pragma unroll
         for (int c = 0; c < CR; ++c) fetch_col<T, L, NT>(sv[c], S + ((long)n * a.C + c) * splane, ln, L, a.KXP);
     }
-    if (CH == 1) fetch_col<T, L, NT>(wf, SWf, ln, L, a.KXP);
+    if (CH == 1) fetch_col<T, L, NT>(wf, SWf + (long)mbeg * splane, ln, L, a.KXP);
     __syncthreads();
-    for (int m = 0; m < a.M; ++m) {
+    for (int m = mbeg; m < mend; ++m) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15;
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(NT) void k_fft_grad_H(FftArgs a) {
             x[pos * kColBS + col] = g;
         }
         __syncthreads();
-        if (CH == 1) fetch_col<T, L, NT>(wf, SWf + (long)min(m + 1, a.M - 1) * splane, ln, L, a.KXP);
+        if (CH == 1) fetch_col<T, L, NT>(wf, SWf + (long)min(m + 1, mend - 1) * splane, ln, L, a.KXP);
         tile_inv<T, P, kColTile, kColBS, NT>(x, tw, tid);
         store_col_tile_rows<T, NT>(x, Tout + ((long)nl * a.M + m) * tplane, a.Hy, 0, a.KXP, a.KX, kx0, tid);
         __syncthreads();
@@ -593,7 +595,7 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
             TNMF_FFT_LAUNCH((k_fft_contract_R<T, L, NTC, 4>), grid, NTC, col_lds);
         }
         case kFftGradH: {
-            const dim3 grid((unsigned)a->planes, tiles, 2);
+            const dim3 grid((unsigned)a->planes, tiles, 2u * (unsigned)a->mgroups);
             if (a->C == 1) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 1>), grid, NTC, col_lds);
             if (a->C == 2) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 2>), grid, NTC, col_lds);
             if (a->C == 3) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 3>), grid, NTC, col_lds);
