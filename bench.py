@@ -247,6 +247,13 @@ def main():
         el2 = time.perf_counter() - t1
         spans2 = nmf2._backend.stop_timeline()
         Wd, Wf = nmf.W, nmf2.W
+        # the formulation's own HBM streams per iteration: row spectra T = N*M*Hy*(Lx/2+1) complex64
+        # read 5x / written 3x, H read and written once, everything else is N*C- or M*C-sized
+        Hy, Hx = (d + a - 1 for d, a in zip(cfg['D'], cfg['A']))
+        Lx = next(L for L in (32, 48, 64, 96, 144, 192, 288, 384, 576) if L >= Hx)
+        t_bytes = n_local * cfg['M'] * Hy * (Lx // 2 + 1) * 8
+        h_bytes = n_local * cfg['M'] * Hy * Hx * 4
+        fft_stream_bytes = 8 * t_bytes + 2 * h_bytes
         fft_variant = {
             'value': args.steps / el2, 'unit': 'MU-iterations/sec', 'ms_per_step': el2 / args.steps * 1e3,
             'kernel_path': nmf2._backend.last_path,
@@ -255,6 +262,11 @@ def main():
             'W_max_rel_diff_vs_direct': float(np.abs(Wf - Wd).max() / np.abs(Wd).max()),
             'energy_after_run': nmf2._energy_function(),
             'speedup_over_direct': (args.steps / el2) / (world * args.steps / elapsed),
+            'roofline': {'bound': 'hbm', 'achieved': fft_stream_bytes / (el2 / args.steps) / 1e9, 'peak': PEAK_HBM_GBS,
+                         'unit': 'GB/s', 'frac': fft_stream_bytes / (el2 / args.steps) / 1e9 / PEAK_HBM_GBS,
+                         'stream_bytes_per_iteration': fft_stream_bytes,
+                         'what': 'whole iteration: bytes the FFT formulation must stream (8 passes over the row '
+                                 'spectra + H read/write) / iteration time'},
         }
         del nmf2
 
