@@ -50,7 +50,7 @@ typedef struct {
 
 /* Kernel family selection (tnmf_hip_ctx_set_path): AUTO picks the MFMA kernels where the shape allows.  FFT is the
  * frequency-domain formulation (the algorithm of the reference's default backend, tnmf/backends/NumPy_FFT.py:16-40):
- * float32 2-D problems with shift shapes up to 576, float64 up to 96. */
+ * float32 2-D problems with shift shapes up to 576, float64 up to 144. */
 enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_FFT = 3 };
 
 int tnmf_hip_abi_version(void);

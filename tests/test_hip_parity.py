@@ -274,7 +274,7 @@ FFT_SHAPES = [
     (2, 1, (5, 6), 2, (5, 6), 'df'),           # 32, 32 (atom as large as the sample)
     (1, 1, (64, 64), 32, (12, 12), 'df'),      # 96, 96
     (5, 5, (24, 40), 3, (3, 7), 'df'),         # 32, 48; more channels than one register group
-    (2, 1, (128, 128), 16, (9, 9), 'f'),       # 144, 144
+    (2, 1, (128, 128), 16, (9, 9), 'df'),      # 144, 144
     (2, 3, (100, 170), 8, (12, 12), 'f'),      # 144, 192
     (1, 3, (256, 200), 8, (12, 12), 'f'),      # 288, 288
     (1, 1, (300, 500), 4, (16, 16), 'f'),      # 384, 576
@@ -286,7 +286,7 @@ FFT_SHAPES = [
 def test_fft_family_against_oracle(shape, dtype, tol):
     N, C, D, M, A, kinds = shape
     if ('d' if dtype == np.float64 else 'f') not in kinds:
-        pytest.skip('float64 transforms are instantiated up to length 96')
+        pytest.skip('float64 transforms are instantiated up to length 144')
     rng = np.random.default_rng(N * 1000 + M)
     V = rng.random((N, C) + D)
     Wn = rng.random((M, C) + A)
@@ -320,6 +320,40 @@ def test_fft_family_against_oracle(shape, dtype, tol):
     be.fused_update_H(V, Wf, Hf, slice(None), sparsity=0., eps=1e-9)   # cached spectra again, new W
     on, op = orc.gradient_H(V, Wo, Hnew, slice(None), 'c')
     assert relmax(be.to_ndarray(Hf), Hnew * on / (op + 1e-9)) < 4 * tol
+
+
+@pytest.mark.parametrize('scenario', ['rgb_full_batch', 'rgb_unfused', 'sparsity', 'inhibition', 'cross_inhibition',
+                                      'Cyclic_MU', 'ASG_MU', 'GSAG_MU', 'stream'])
+def test_fft_family_reproduces_reference_known_answers_f64(scenario):
+    """The hard-coded energies of the reference's own tests (float64), this time through path='fft': full batch, the
+    unfused front-end path (gradient primitives + elementwise MU), sparsity and inhibition terms, mini-batch schedules
+    on slices of H (spectrum cache keyed by the slice) and the streaming fit."""
+    np.random.seed(42)
+    kw = dict(n_atoms=10, atom_shape=(7, 7), backend='hip', path='fft')
+    if scenario in ('rgb_full_batch', 'rgb_unfused'):
+        nmf = TransformInvariantNMF(use_fused_updates=scenario == 'rgb_full_batch', **kw)
+        nmf.fit(racoon_rgb_V(), sparsity_H=0.1, n_iterations=10)
+        E = 268.14423                                              # tnmf/tests/test_backends.py:18
+    elif scenario in ('sparsity', 'inhibition', 'cross_inhibition'):
+        fit_kw, ctor_kw, E = {                                     # tnmf/tests/test_sparsity_inhibition.py:20-52
+            'sparsity': (dict(sparsity_H=1.0), dict(), 2429.69334),
+            'inhibition': (dict(inhibition_strength=1.0), dict(inhibition_range=(3, 3)), 1119.00855),
+            'cross_inhibition': (dict(cross_atom_inhibition_strength=0.5), dict(inhibition_range=(3, 3)), 724.238350),
+        }[scenario]
+        nmf = TransformInvariantNMF(**kw, **ctor_kw)
+        nmf.fit(racoon_rgb_V(), n_iterations=25, **fit_kw)
+    elif scenario == 'stream':
+        nmf = TransformInvariantNMF(**kw)
+        nmf.fit((v for v in racoon_patches_V()), sparsity_H=0.1, algorithm=MiniBatchAlgorithm.ASAG_MU,
+                subsample_size=50, batch_size=3, n_epochs=5, sag_lambda=0.8)
+        E = 96.7375921                                             # tnmf/tests/test_stream.py:25
+    else:
+        nmf = TransformInvariantNMF(**kw)
+        nmf.fit_minibatches(racoon_patches_V(), sparsity_H=0.1, algorithm=MiniBatchAlgorithm[scenario], batch_size=3,
+                            n_epochs=5, sag_lambda=0.8)
+        E = {'Cyclic_MU': 14434.02658, 'ASG_MU': 4558.86695, 'GSAG_MU': 14310.92041}[scenario]   # test_minibatch.py:18-25
+    assert nmf._backend.last_path == 'fft'
+    assert np.isclose(nmf._energy_function(), E)
 
 
 @pytest.mark.parametrize('C,D,M,A', BASELINE_SHAPES, ids=['config2', 'config3', 'config4', 'config5'])

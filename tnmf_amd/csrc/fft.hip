@@ -19,7 +19,7 @@ const int kLens[] = {32, 48, 64, 96, 144, 192, 288, 384, 576};
 
 int pick_len(int h, int dtype) {
     for (int L : kLens)
-        if (L >= h && (dtype == 0 || L <= 96)) return L;
+        if (L >= h && (dtype == 0 || L <= 144)) return L;
     return 0;
 }
 
