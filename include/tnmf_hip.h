@@ -64,10 +64,11 @@ int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom);
 int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path);
 /* Name of the kernel family the last primitive call on this ctx dispatched to ("generic", "mfma", "fft"). */
 const char *tnmf_hip_ctx_last_path(const tnmf_hip_ctx *ctx);
-/* FFT family only: the library may keep the row spectra of the activations H it transformed or updated last and
- * reuse them while the same H pointer comes back (the reference's NumPy_CachingFFT.py:22-140 caches spectra the same
- * way).  Off by default.  A caller that enables it vouches that H changes only through this library, and calls
- * tnmf_hip_ctx_invalidate() after writing H by any other means. */
+/* FFT family only: the library may keep the row spectra of the activations H it transformed or updated last, and the
+ * spectra of the samples V it transformed last, and reuse them while the same pointers and geometry come back (the
+ * reference's NumPy_CachingFFT.py:22-140 caches spectra the same way).  Off by default.  A caller that enables it
+ * vouches that H changes only through this library and V not at all, and calls tnmf_hip_ctx_invalidate() after
+ * writing either by any other means. */
 int tnmf_hip_ctx_set_cache(tnmf_hip_ctx *ctx, int enable);
 int tnmf_hip_ctx_invalidate(tnmf_hip_ctx *ctx);
 

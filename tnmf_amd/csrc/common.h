@@ -19,11 +19,16 @@ struct Geo {
 struct FftState {
     void *ws;
     size_t ws_bytes;
-    bool cache_enabled;      // the caller vouches that H only changes through this library (tnmf_hip_ctx_set_cache)
+    bool cache_enabled;      // the caller vouches that H and V only change through this library or are announced
+                             // with tnmf_hip_ctx_invalidate (tnmf_hip_ctx_set_cache)
     bool T_valid;            // the workspace holds the row spectra of T_owner for T_geo / T_dtype
     const void *T_owner;
     Geo T_geo;
     int T_dtype;
+    bool V_valid;            // ... and the full spectra of the samples V_owner (same geometry rules)
+    const void *V_owner;
+    Geo V_geo;
+    int V_dtype;
 };
 
 struct tnmf_hip_ctx {

@@ -55,7 +55,7 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
     l->KX = l->Lx / 2 + 1;
     l->KXP = (int)align_up((size_t)l->KX, 16);
     l->csz = dtype == 0 ? 8 : 16;
-    const int tiles = cdiv(l->KX, 16);
+    const int tiles = cdiv(l->KX, l->Ly > 384 ? 8 : 16);   // LenCfg<Ly>::col_tile of fft_kernels.h
     int ng = cdiv(2048, g.M * tiles);
     if (ng > 16) ng = 16;
     if (ng > g.N) ng = g.N;
@@ -75,7 +75,7 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
     if (chunk < 1) chunk = 1;
     if (chunk > g.N) chunk = g.N > 0 ? g.N : 1;
     l->chunk = (int)chunk;
-    int mg = cdiv(1024, l->chunk * tiles * 2);
+    int mg = cdiv(1024, l->chunk * cdiv(l->KX, 16) * 2);   // the H-gradient kernel always takes 16-column tiles
     if (mg > g.M) mg = g.M;
     if (mg < 1) mg = 1;
     l->mper = cdiv(g.M, mg);
@@ -117,6 +117,7 @@ int ensure_ws(tnmf_hip_ctx *ctx, size_t bytes) {
         f.ws_bytes = 0;
     }
     f.T_valid = false;
+    f.V_valid = false;
     const size_t want = align_up(bytes, 1 << 20);
     if (hipMalloc(&f.ws, want) != hipSuccess) {
         (void)hipGetLastError();
@@ -234,6 +235,23 @@ void T_mark(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
     f.T_dtype = dtype;
 }
 
+bool same_geo(const Geo &a, const Geo &b) {
+    return a.N == b.N && a.M == b.M && a.C == b.C && a.Dy == b.Dy && a.Dx == b.Dx && a.Ay == b.Ay && a.Ax == b.Ax;
+}
+
+// full spectra of the samples into SV (skipped when the cache holds them: V never changes during a fit)
+int spectra_V(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, hipStream_t s) {
+    FftState &f = ctx->fft;
+    if (f.cache_enabled && f.V_valid && f.V_owner == V && f.V_dtype == dtype && same_geo(f.V_geo, g)) return TNMF_OK;
+    f.V_valid = false;
+    CHECK(forward_planes(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SV), s));
+    f.V_valid = f.cache_enabled;
+    f.V_owner = V;
+    f.V_geo = g;
+    f.V_dtype = dtype;
+    return TNMF_OK;
+}
+
 // row spectra of H into the workspace (skipped when the cache holds them)
 int rows_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *H, hipStream_t s) {
     if (T_is_current(ctx, g, dtype, H)) return TNMF_OK;
@@ -265,13 +283,17 @@ bool fft_has(const Geo &g, int dtype) {
     return pick_len(g.Hy, dtype) != 0 && pick_len(g.Hx, dtype) != 0;
 }
 
-void fft_invalidate(tnmf_hip_ctx *ctx) { ctx->fft.T_valid = false; }
+void fft_invalidate(tnmf_hip_ctx *ctx) {
+    ctx->fft.T_valid = false;
+    ctx->fft.V_valid = false;
+}
 
 void fft_release(tnmf_hip_ctx *ctx) {
     if (ctx->fft.ws) (void)hipFree(ctx->fft.ws);
     ctx->fft.ws = nullptr;
     ctx->fft.ws_bytes = 0;
     ctx->fft.T_valid = false;
+    ctx->fft.V_valid = false;
 }
 
 int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
@@ -309,7 +331,7 @@ namespace {
 int grad_H_spectra(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, const void *R,
                    const void *W, hipStream_t s) {
     CHECK(spectra_W(ctx, g, l, dtype, W, false, true, s));
-    CHECK(forward_planes(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SV), s));
+    CHECK(spectra_V(ctx, g, l, dtype, V, s));
     return forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s);
 }
 
@@ -388,7 +410,7 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l));
     CHECK(rows_of_H(ctx, g, l, dtype, H, s));
-    CHECK(forward_planes(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SV), s));
+    CHECK(spectra_V(ctx, g, l, dtype, V, s));
     CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
     FftArgs a = base_args(g, l);
     a.src0 = at(ctx, l.T);

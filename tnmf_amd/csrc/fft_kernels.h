@@ -12,18 +12,26 @@
 
 namespace {
 
-constexpr int kColTile = 16;   // kx columns per column-kernel tile
-constexpr int kColBS = 17;     // position stride of a column tile in LDS (odd: spreads the stage-3 blocks over banks)
+// A column kernel works on a tile of LenCfg<L>::col_tile kx columns; its LDS position stride is col_tile + 1 (odd:
+// spreads the stage-3 blocks over the banks).
 
 template <int L>
 struct LenCfg {
+    static constexpr int col_tile = L > 384 ? 8 : 16;   // kx columns per column-kernel tile (a power of two); the long
+                                                        // transforms take narrow tiles to keep the per-thread share at 9
     static constexpr int col_threads = L > 192 ? 512 : 256;
-    static constexpr int col_elems = L * kColTile / col_threads;   // tile elements per thread
+    static constexpr int col_elems = L * col_tile / col_threads;   // tile elements per thread
     static constexpr int row_pairs = L > 288 ? 8 : 16;
     static constexpr int row_threads = 256;
     static constexpr int mu_pairs = L > 288 ? 4 : 8;   // the fused update kernel keeps its tile small: more blocks per CU
     // channels per pass of the contraction kernels (accumulators live in registers)
-    static constexpr int cg_W = 2;   // the W-gradient kernel carries two accumulator sets per channel
+};
+
+// tile width of a column kernel: WIDE kernels (the H-gradient kernel, which stores two activation-sized streams and
+// needs whole 128-byte segments for that) always take 16 columns
+template <int L, bool WIDE>
+struct ColTile {
+    static constexpr int v = WIDE ? 16 : LenCfg<L>::col_tile;
 };
 
 template <typename T, int L>
@@ -273,24 +281,24 @@ __global__ __launch_bounds__(NT) void k_fft_rows_mu(FftArgs a) {
 // ---- column kernels ---------------------------------------------------------------------------------------------
 
 // tile <- rows [0, rows) x columns [kx0, kx0+16) of one plane of row spectra; zero elsewhere
-template <typename T, int L, int NT>
+template <typename T, int L, int NT, bool WIDE>
 __device__ __forceinline__ void load_col_tile(cplx<T> *x, const cplx<T> *src, int rows, int KXP, int KX, int kx0,
                                               int tid) {
-    for (int idx = tid; idx < L * kColTile; idx += NT) {
-        const int y = idx >> 4, col = idx & 15, kx = kx0 + col;
+    for (int idx = tid; idx < L * ColTile<L, WIDE>::v; idx += NT) {
+        const int y = idx / ColTile<L, WIDE>::v, col = idx % ColTile<L, WIDE>::v, kx = kx0 + col;
         cplx<T> v = {0, 0};
         if (y < rows && kx < KX) v = src[(long)y * KXP + kx];
-        x[y * kColBS + col] = v;
+        x[y * (ColTile<L, WIDE>::v + 1) + col] = v;
     }
 }
 
 // rows [yoff, yoff+rows) of the tile -> one plane of row spectra
-template <typename T, int NT>
+template <typename T, int L, int NT, bool WIDE>
 __device__ __forceinline__ void store_col_tile_rows(const cplx<T> *x, cplx<T> *dst, int rows, int yoff, int KXP, int KX,
                                                     int kx0, int tid) {
-    for (int idx = tid; idx < rows * kColTile; idx += NT) {
-        const int y = idx >> 4, col = idx & 15, kx = kx0 + col;
-        if (kx < KX) dst[(long)y * KXP + kx] = x[(y + yoff) * kColBS + col];
+    for (int idx = tid; idx < rows * ColTile<L, WIDE>::v; idx += NT) {
+        const int y = idx / ColTile<L, WIDE>::v, col = idx % ColTile<L, WIDE>::v, kx = kx0 + col;
+        if (kx < KX) dst[(long)y * KXP + kx] = x[(y + yoff) * (ColTile<L, WIDE>::v + 1) + col];
     }
 }
 
@@ -298,17 +306,18 @@ __device__ __forceinline__ void store_col_tile_rows(const cplx<T> *x, cplx<T> *d
 template <typename T, int L, int NT>
 __global__ __launch_bounds__(NT) void k_fft_cols_fwd(FftArgs a) {
     using P = FftPlanFor<T, L>;
+    constexpr bool WIDE = false;
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
-    cplx<T> *tw = x + L * kColBS;
-    const int tid = threadIdx.x, kx0 = blockIdx.x * kColTile;
+    cplx<T> *tw = x + L * (ColTile<L, WIDE>::v + 1);
+    const int tid = threadIdx.x, kx0 = blockIdx.x * ColTile<L, WIDE>::v;
     const long plane = blockIdx.y;
     make_twiddles<T, L>(tw, tid, NT);
-    load_col_tile<T, L, NT>(x, static_cast<const cplx<T> *>(a.src0) + plane * ((long)a.rows * a.KXP), a.rows, a.KXP,
+    load_col_tile<T, L, NT, WIDE>(x, static_cast<const cplx<T> *>(a.src0) + plane * ((long)a.rows * a.KXP), a.rows, a.KXP,
                             a.KX, kx0, tid);
     __syncthreads();
-    tile_fwd<T, P, kColTile, kColBS, NT>(x, tw, tid);
-    store_col_tile_rows<T, NT>(x, static_cast<cplx<T> *>(a.dst0) + plane * ((long)L * a.KXP), L, 0, a.KXP, a.KX, kx0,
+    tile_fwd<T, P, ColTile<L, WIDE>::v, (ColTile<L, WIDE>::v + 1), NT>(x, tw, tid);
+    store_col_tile_rows<T, L, NT, WIDE>(x, static_cast<cplx<T> *>(a.dst0) + plane * ((long)L * a.KXP), L, 0, a.KXP, a.KX, kx0,
                                tid);
 }
 
@@ -316,17 +325,18 @@ __global__ __launch_bounds__(NT) void k_fft_cols_fwd(FftArgs a) {
 template <typename T, int L, int NT>
 __global__ __launch_bounds__(NT) void k_fft_cols_inv(FftArgs a) {
     using P = FftPlanFor<T, L>;
+    constexpr bool WIDE = false;
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
-    cplx<T> *tw = x + L * kColBS;
-    const int tid = threadIdx.x, kx0 = blockIdx.x * kColTile;
+    cplx<T> *tw = x + L * (ColTile<L, WIDE>::v + 1);
+    const int tid = threadIdx.x, kx0 = blockIdx.x * ColTile<L, WIDE>::v;
     const long plane = blockIdx.y;
     make_twiddles<T, L>(tw, tid, NT);
-    load_col_tile<T, L, NT>(x, static_cast<const cplx<T> *>(a.src0) + plane * ((long)L * a.KXP), L, a.KXP, a.KX, kx0,
+    load_col_tile<T, L, NT, WIDE>(x, static_cast<const cplx<T> *>(a.src0) + plane * ((long)L * a.KXP), L, a.KXP, a.KX, kx0,
                             tid);
     __syncthreads();
-    tile_inv<T, P, kColTile, kColBS, NT>(x, tw, tid);
-    store_col_tile_rows<T, NT>(x, static_cast<cplx<T> *>(a.dst0) + plane * ((long)a.rows * a.KXP), a.rows, a.yoff,
+    tile_inv<T, P, ColTile<L, WIDE>::v, (ColTile<L, WIDE>::v + 1), NT>(x, tw, tid);
+    store_col_tile_rows<T, L, NT, WIDE>(x, static_cast<cplx<T> *>(a.dst0) + plane * ((long)a.rows * a.KXP), a.rows, a.yoff,
                                a.KXP, a.KX, kx0, tid);
 }
 
@@ -337,28 +347,28 @@ __global__ __launch_bounds__(NT) void k_fft_cols_inv(FftArgs a) {
 struct ColLane {
     int y0, kxc;   // first row of the thread, clamped kx
 };
-template <int NT>
+template <int L, int NT, bool WIDE>
 __device__ __forceinline__ ColLane col_lane(int KX, int kx0, int tid) {
-    return {tid >> 4, min(kx0 + (tid & 15), KX - 1)};
+    return {tid / ColTile<L, WIDE>::v, min(kx0 + (tid % ColTile<L, WIDE>::v), KX - 1)};
 }
 
 // pre[e] <- base[min(row_e, rows-1)][kx]  (base: one plane, uniform)
-template <typename T, int L, int NT>
+template <typename T, int L, int NT, bool WIDE>
 __device__ __forceinline__ void fetch_col(cplx<T> *pre, const cplx<T> *base, ColLane ln, int rows, int KXP) {
-    constexpr int E = L * kColTile / NT;
+    constexpr int E = L * ColTile<L, WIDE>::v / NT;
 #pragma unroll
-    for (int e = 0; e < E; ++e) pre[e] = base[(unsigned)(min(ln.y0 + e * (NT / 16), rows - 1) * KXP + ln.kxc)];
+    for (int e = 0; e < E; ++e) pre[e] = base[(unsigned)(min(ln.y0 + e * (NT / ColTile<L, WIDE>::v), rows - 1) * KXP + ln.kxc)];
 }
 
-template <typename T, int L, int NT>
+template <typename T, int L, int NT, bool WIDE>
 __device__ __forceinline__ void commit_col_tile(cplx<T> *x, const cplx<T> *pre, int rows, int KX, int kx0, int tid) {
-    constexpr int E = L * kColTile / NT;
+    constexpr int E = L * ColTile<L, WIDE>::v / NT;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int idx = tid + e * NT, y = idx >> 4, col = idx & 15;
+        const int idx = tid + e * NT, y = idx / ColTile<L, WIDE>::v, col = idx % ColTile<L, WIDE>::v;
         cplx<T> v = pre[e];
         if (y >= rows || kx0 + col >= KX) v = {0, 0};
-        x[y * kColBS + col] = v;
+        x[y * (ColTile<L, WIDE>::v + 1) + col] = v;
     }
 }
 
@@ -368,35 +378,56 @@ __device__ __forceinline__ void commit_col_tile(cplx<T> *x, const cplx<T> *pre, 
 template <typename T, int L, int NT, int CG>
 __global__ __launch_bounds__(NT) void k_fft_contract_R(FftArgs a) {
     using P = FftPlanFor<T, L>;
-    constexpr int E = L * kColTile / NT;
+    constexpr bool WIDE = false;
+    constexpr int E = L * ColTile<L, WIDE>::v / NT;
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
-    cplx<T> *tw = x + L * kColBS;
-    const int tid = threadIdx.x, n = blockIdx.x, kx0 = blockIdx.y * kColTile, c0 = blockIdx.z * CG;
+    cplx<T> *tw = x + L * (ColTile<L, WIDE>::v + 1);
+    const int tid = threadIdx.x, n = blockIdx.x, kx0 = blockIdx.y * ColTile<L, WIDE>::v, c0 = blockIdx.z * CG;
     make_twiddles<T, L>(tw, tid, NT);
     const cplx<T> *Tsrc = static_cast<const cplx<T> *>(a.src0);
     const cplx<T> *SW = static_cast<const cplx<T> *>(a.src1);
     const long tplane = (long)a.Hy * a.KXP, splane = (long)L * a.KXP;
     cplx<T> acc[CG][E], pre[E];
-    const ColLane ln = col_lane<NT>(a.KX, kx0, tid);
+    const ColLane ln = col_lane<L, NT, WIDE>(a.KX, kx0, tid);
 #pragma unroll
     for (int cc = 0; cc < CG; ++cc)
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[cc][e] = {0, 0};
-    fetch_col<T, L, NT>(pre, Tsrc + (long)n * a.M * tplane, ln, a.Hy, a.KXP);
+    fetch_col<T, L, NT, WIDE>(pre, Tsrc + (long)n * a.M * tplane, ln, a.Hy, a.KXP);
     for (int m = 0; m < a.M; ++m) {
-        commit_col_tile<T, L, NT>(x, pre, a.Hy, a.KX, kx0, tid);
+        commit_col_tile<T, L, NT, WIDE>(x, pre, a.Hy, a.KX, kx0, tid);
         __syncthreads();
-        fetch_col<T, L, NT>(pre, Tsrc + ((long)n * a.M + min(m + 1, a.M - 1)) * tplane, ln, a.Hy, a.KXP);
-        tile_fwd<T, P, kColTile, kColBS, NT>(x, tw, tid);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15;
-            const cplx<T> h = x[pos * kColBS + col];
+        // W spectra of this atom: the first channel is fetched under the transform, the others while the previous
+        // channel is accumulated (two register buffers)
+        // (only while the per-thread tile share is small: at E = 18 the buffers would spill)
+        constexpr bool PIPE = E <= 12;
+        cplx<T> wb[PIPE ? 2 : 1][PIPE ? E : 1];
+        if (PIPE) fetch_col<T, L, NT, WIDE>(wb[0], SW + ((long)m * a.C + min(c0, a.C - 1)) * splane, ln, L, a.KXP);
+        fetch_col<T, L, NT, WIDE>(pre, Tsrc + ((long)n * a.M + min(m + 1, a.M - 1)) * tplane, ln, a.Hy, a.KXP);
+        tile_fwd<T, P, ColTile<L, WIDE>::v, (ColTile<L, WIDE>::v + 1), NT>(x, tw, tid);
+        if constexpr (PIPE) {
 #pragma unroll
             for (int cc = 0; cc < CG; ++cc) {
-                const cplx<T> *b = SW + ((long)m * a.C + min(c0 + cc, a.C - 1)) * splane;
-                cfma(acc[cc][e], h, b[(unsigned)(pos * a.KXP + ln.kxc)]);
+                if (cc + 1 < CG)
+                    fetch_col<T, L, NT, WIDE>(wb[(cc + 1) & 1], SW + ((long)m * a.C + min(c0 + cc + 1, a.C - 1)) * splane, ln,
+                                        L, a.KXP);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int idx = tid + e * NT, pos = idx / ColTile<L, WIDE>::v, col = idx % ColTile<L, WIDE>::v;
+                    cfma(acc[cc][e], x[pos * (ColTile<L, WIDE>::v + 1) + col], wb[cc & 1][e]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int idx = tid + e * NT, pos = idx / ColTile<L, WIDE>::v, col = idx % ColTile<L, WIDE>::v;
+                const cplx<T> h = x[pos * (ColTile<L, WIDE>::v + 1) + col];
+#pragma unroll
+                for (int cc = 0; cc < CG; ++cc) {
+                    const cplx<T> *b = SW + ((long)m * a.C + min(c0 + cc, a.C - 1)) * splane;
+                    cfma(acc[cc][e], h, b[(unsigned)(pos * a.KXP + ln.kxc)]);
+                }
             }
         }
         __syncthreads();
@@ -407,7 +438,7 @@ __global__ __launch_bounds__(NT) void k_fft_contract_R(FftArgs a) {
         if (c0 + cc >= a.C) continue;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15, kx = kx0 + col;
+            const int idx = tid + e * NT, pos = idx / ColTile<L, WIDE>::v, col = idx % ColTile<L, WIDE>::v, kx = kx0 + col;
             if (kx < a.KX) SR[((long)n * a.C + c0 + cc) * splane + (long)pos * a.KXP + kx] = acc[cc][e];
         }
     }
@@ -423,47 +454,60 @@ __global__ __launch_bounds__(NT) void k_fft_contract_R(FftArgs a) {
 template <typename T, int L, int NT, int CH>
 __global__ __launch_bounds__(NT) void k_fft_grad_H(FftArgs a) {
     using P = FftPlanFor<T, L>;
-    constexpr int E = L * kColTile / NT, CR = CH > 0 ? CH : 1;
+    constexpr bool WIDE = true;
+    constexpr int E = L * ColTile<L, WIDE>::v / NT, CR = CH > 0 ? CH : 1;
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
-    cplx<T> *tw = x + L * kColBS;
-    const int tid = threadIdx.x, nl = blockIdx.x, n = a.n0 + nl, kx0 = blockIdx.y * kColTile;
+    cplx<T> *tw = x + L * (ColTile<L, WIDE>::v + 1);
+    const int tid = threadIdx.x, nl = blockIdx.x, n = a.n0 + nl, kx0 = blockIdx.y * ColTile<L, WIDE>::v;
     make_twiddles<T, L>(tw, tid, NT);
     const int which = blockIdx.z & 1, mbeg = (blockIdx.z >> 1) * a.mper, mend = min(a.M, mbeg + a.mper);
     const cplx<T> *S = static_cast<const cplx<T> *>(which ? a.src1 : a.src0);
     const cplx<T> *SWf = static_cast<const cplx<T> *>(a.src2);
     cplx<T> *Tout = static_cast<cplx<T> *>(which ? a.dst1 : a.dst0);
     const long tplane = (long)a.Hy * a.KXP, splane = (long)L * a.KXP;
-    const ColLane ln = col_lane<NT>(a.KX, kx0, tid);
-    cplx<T> sv[CR][E], wf[CH == 1 ? E : 1];
+    const ColLane ln = col_lane<L, NT, WIDE>(a.KX, kx0, tid);
+    cplx<T> sv[CR][E], wb[CH > 0 ? 2 : 1][CH > 0 ? E : 1];
     if (CH > 0) {
 #pragma unroll
-        for (int c = 0; c < CR; ++c) fetch_col<T, L, NT>(sv[c], S + ((long)n * a.C + c) * splane, ln, L, a.KXP);
+        for (int c = 0; c < CR; ++c) fetch_col<T, L, NT, WIDE>(sv[c], S + ((long)n * a.C + c) * splane, ln, L, a.KXP);
+        fetch_col<T, L, NT, WIDE>(wb[0], SWf + (long)mbeg * a.C * splane, ln, L, a.KXP);
     }
-    if (CH == 1) fetch_col<T, L, NT>(wf, SWf + (long)mbeg * splane, ln, L, a.KXP);
     __syncthreads();
     for (int m = mbeg; m < mend; ++m) {
+        if (CH > 0) {
+            // channel 0 of this atom arrived under the previous inverse transform; the others are fetched while the
+            // previous channel is multiplied (two register buffers)
+            cplx<T> g[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15;
-            cplx<T> g = {0, 0};
-            if (CH == 1) {
-                cfma(g, sv[0][e], wf[e]);
-            } else if (CH > 1) {
+            for (int e = 0; e < E; ++e) g[e] = {0, 0};
 #pragma unroll
-                for (int c = 0; c < CR; ++c)
-                    cfma(g, sv[c][e], (SWf + ((long)m * a.C + c) * splane)[(unsigned)(pos * a.KXP + ln.kxc)]);
-            } else {
+            for (int c = 0; c < CR; ++c) {
+                if (c + 1 < CR)
+                    fetch_col<T, L, NT, WIDE>(wb[(c + 1) & 1], SWf + ((long)m * a.C + c + 1) * splane, ln, L, a.KXP);
+#pragma unroll
+                for (int e = 0; e < E; ++e) cfma(g[e], sv[c][e], wb[c & 1][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int idx = tid + e * NT;
+                x[(idx / ColTile<L, WIDE>::v) * (ColTile<L, WIDE>::v + 1) + (idx % ColTile<L, WIDE>::v)] = g[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int idx = tid + e * NT, pos = idx / ColTile<L, WIDE>::v, col = idx % ColTile<L, WIDE>::v;
+                cplx<T> g = {0, 0};
                 for (int c = 0; c < a.C; ++c)
                     cfma(g, (S + ((long)n * a.C + c) * splane)[(unsigned)(pos * a.KXP + ln.kxc)],
                          (SWf + ((long)m * a.C + c) * splane)[(unsigned)(pos * a.KXP + ln.kxc)]);
+                x[pos * (ColTile<L, WIDE>::v + 1) + col] = g;
             }
-            x[pos * kColBS + col] = g;
         }
         __syncthreads();
-        if (CH == 1) fetch_col<T, L, NT>(wf, SWf + (long)min(m + 1, mend - 1) * splane, ln, L, a.KXP);
-        tile_inv<T, P, kColTile, kColBS, NT>(x, tw, tid);
-        store_col_tile_rows<T, NT>(x, Tout + ((long)nl * a.M + m) * tplane, a.Hy, 0, a.KXP, a.KX, kx0, tid);
+        if (CH > 0) fetch_col<T, L, NT, WIDE>(wb[0], SWf + (long)min(m + 1, mend - 1) * a.C * splane, ln, L, a.KXP);
+        tile_inv<T, P, ColTile<L, WIDE>::v, (ColTile<L, WIDE>::v + 1), NT>(x, tw, tid);
+        store_col_tile_rows<T, L, NT, WIDE>(x, Tout + ((long)nl * a.M + m) * tplane, a.Hy, 0, a.KXP, a.KX, kx0, tid);
         __syncthreads();
     }
 }
@@ -474,11 +518,12 @@ __global__ __launch_bounds__(NT) void k_fft_grad_H(FftArgs a) {
 template <typename T, int L, int NT, int CG>
 __global__ __launch_bounds__(NT) void k_fft_grad_W(FftArgs a) {
     using P = FftPlanFor<T, L>;
-    constexpr int E = L * kColTile / NT;
+    constexpr bool WIDE = false;
+    constexpr int E = L * ColTile<L, WIDE>::v / NT;
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
-    cplx<T> *tw = x + L * kColBS;
-    const int tid = threadIdx.x, m = blockIdx.x, kx0 = blockIdx.y * kColTile;
+    cplx<T> *tw = x + L * (ColTile<L, WIDE>::v + 1);
+    const int tid = threadIdx.x, m = blockIdx.x, kx0 = blockIdx.y * ColTile<L, WIDE>::v;
     const int grp = blockIdx.z % a.ngroups, c0 = (blockIdx.z / a.ngroups) * CG;
     make_twiddles<T, L>(tw, tid, NT);
     const cplx<T> *Tsrc = static_cast<const cplx<T> *>(a.src0);
@@ -494,25 +539,26 @@ __global__ __launch_bounds__(NT) void k_fft_grad_W(FftArgs a) {
             ap[cc][e] = {0, 0};
         }
     const int nbeg = grp * a.nper, nend = min(a.N, nbeg + a.nper);
-    const ColLane ln = col_lane<NT>(a.KX, kx0, tid);
-    if (nbeg < nend) fetch_col<T, L, NT>(pre, Tsrc + ((long)nbeg * a.M + m) * tplane, ln, a.Hy, a.KXP);
+    const ColLane ln = col_lane<L, NT, WIDE>(a.KX, kx0, tid);
+    if (nbeg < nend) fetch_col<T, L, NT, WIDE>(pre, Tsrc + ((long)nbeg * a.M + m) * tplane, ln, a.Hy, a.KXP);
     for (int n = nbeg; n < nend; ++n) {
-        commit_col_tile<T, L, NT>(x, pre, a.Hy, a.KX, kx0, tid);
+        commit_col_tile<T, L, NT, WIDE>(x, pre, a.Hy, a.KX, kx0, tid);
         __syncthreads();
-        cplx<T> v[CG == 1 ? E : 1], r[CG == 1 ? E : 1];
-        if (CG == 1) {
-            fetch_col<T, L, NT>(v, SV + ((long)n * a.C + c0) * splane, ln, L, a.KXP);
-            fetch_col<T, L, NT>(r, SR + ((long)n * a.C + c0) * splane, ln, L, a.KXP);
+        constexpr bool PRE = CG == 1 && E <= 12;   // at E = 18 the staged spectra would spill
+        cplx<T> v[PRE ? E : 1], r[PRE ? E : 1];
+        if (PRE) {
+            fetch_col<T, L, NT, WIDE>(v, SV + ((long)n * a.C + c0) * splane, ln, L, a.KXP);
+            fetch_col<T, L, NT, WIDE>(r, SR + ((long)n * a.C + c0) * splane, ln, L, a.KXP);
         }
-        fetch_col<T, L, NT>(pre, Tsrc + ((long)min(n + 1, nend - 1) * a.M + m) * tplane, ln, a.Hy, a.KXP);
-        tile_fwd<T, P, kColTile, kColBS, NT>(x, tw, tid);
+        fetch_col<T, L, NT, WIDE>(pre, Tsrc + ((long)min(n + 1, nend - 1) * a.M + m) * tplane, ln, a.Hy, a.KXP);
+        tile_fwd<T, P, ColTile<L, WIDE>::v, (ColTile<L, WIDE>::v + 1), NT>(x, tw, tid);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15;
-            const cplx<T> h = x[pos * kColBS + col];
-            if (CG == 1) {
-                cfmac(an[0][e], h, v[e]);
-                cfmac(ap[0][e], h, r[e]);
+            const int idx = tid + e * NT, pos = idx / ColTile<L, WIDE>::v, col = idx % ColTile<L, WIDE>::v;
+            const cplx<T> h = x[pos * (ColTile<L, WIDE>::v + 1) + col];
+            if (PRE) {
+                cfmac(an[0][e], h, v[PRE ? e : 0]);
+                cfmac(ap[0][e], h, r[PRE ? e : 0]);
             } else {
 #pragma unroll
                 for (int cc = 0; cc < CG; ++cc) {
@@ -532,7 +578,7 @@ __global__ __launch_bounds__(NT) void k_fft_grad_W(FftArgs a) {
         if (c0 + cc >= a.C) continue;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int idx = tid + e * NT, pos = idx >> 4, col = idx & 15, kx = kx0 + col;
+            const int idx = tid + e * NT, pos = idx / ColTile<L, WIDE>::v, col = idx % ColTile<L, WIDE>::v, kx = kx0 + col;
             if (kx < a.KX) {
                 const long o = ((long)m * a.C + c0 + cc) * splane + (long)pos * a.KXP + kx;
                 Gn[o] = an[cc][e];
@@ -569,10 +615,11 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
     using Cfg = LenCfg<L>;
     constexpr int NB = Cfg::row_pairs, NTR = Cfg::row_threads, NTC = Cfg::col_threads;
     constexpr size_t row_tile = (size_t)L * (NB + 1) * sizeof(cplx<T>), tw_bytes = (size_t)L * sizeof(cplx<T>);
-    constexpr size_t col_lds = (size_t)L * kColBS * sizeof(cplx<T>) + tw_bytes;
-    if (row_tile * 2 + tw_bytes > 160 * 1024 || col_lds > 160 * 1024) return TNMF_E_UNSUPPORTED;
+    constexpr size_t col_lds = (size_t)L * (LenCfg<L>::col_tile + 1) * sizeof(cplx<T>) + tw_bytes;
+    constexpr size_t wide_lds = (size_t)L * 17 * sizeof(cplx<T>) + tw_bytes;
+    if (row_tile * 2 + tw_bytes > 160 * 1024 || col_lds > 160 * 1024 || wide_lds > 160 * 1024) return TNMF_E_UNSUPPORTED;
     const dim3 rgrid((unsigned)cdiv(a->rows, 2 * NB), (unsigned)a->planes);
-    const unsigned tiles = (unsigned)cdiv(a->KX, kColTile);
+    const unsigned tiles = (unsigned)cdiv(a->KX, LenCfg<L>::col_tile), wide_tiles = (unsigned)cdiv(a->KX, 16);
     switch (op) {
         case kFftRowsFwd: TNMF_FFT_LAUNCH((k_fft_rows_fwd<T, L, NB, NTR>), rgrid, NTR, row_tile + tw_bytes);
         case kFftRowsInv: TNMF_FFT_LAUNCH((k_fft_rows_inv<T, L, NB, NTR, 0>), rgrid, NTR, row_tile + tw_bytes);
@@ -595,19 +642,21 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
             TNMF_FFT_LAUNCH((k_fft_contract_R<T, L, NTC, 4>), grid, NTC, col_lds);
         }
         case kFftGradH: {
-            const dim3 grid((unsigned)a->planes, tiles, 2u * (unsigned)a->mgroups);
-            if (a->C == 1) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 1>), grid, NTC, col_lds);
-            if (a->C == 2) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 2>), grid, NTC, col_lds);
-            if (a->C == 3) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 3>), grid, NTC, col_lds);
-            if (a->C == 4) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 4>), grid, NTC, col_lds);
-            TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 0>), grid, NTC, col_lds);
+            const dim3 grid((unsigned)a->planes, wide_tiles, 2u * (unsigned)a->mgroups);
+            if (a->C == 1) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 1>), grid, NTC, wide_lds);
+            if (a->C == 2) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 2>), grid, NTC, wide_lds);
+            if (a->C == 3) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 3>), grid, NTC, wide_lds);
+            if (a->C == 4) TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 4>), grid, NTC, wide_lds);
+            TNMF_FFT_LAUNCH((k_fft_grad_H<T, L, NTC, 0>), grid, NTC, wide_lds);
         }
-        case kFftGradW:
-            if (a->C == 1)
-                TNMF_FFT_LAUNCH((k_fft_grad_W<T, L, NTC, 1>), dim3((unsigned)a->M, tiles, (unsigned)a->ngroups), NTC,
-                                col_lds);
-            TNMF_FFT_LAUNCH((k_fft_grad_W<T, L, NTC, Cfg::cg_W>),
-                            dim3((unsigned)a->M, tiles, (unsigned)(a->ngroups * cdiv(a->C, Cfg::cg_W))), NTC, col_lds);
+        case kFftGradW: {
+            // channels per pass: two accumulator sets per channel live in registers
+            const int cg = a->C <= 2 ? a->C : (Cfg::col_elems <= 9 ? 3 : 2);
+            const dim3 grid((unsigned)a->M, tiles, (unsigned)(a->ngroups * cdiv(a->C, cg)));
+            if (cg == 1) TNMF_FFT_LAUNCH((k_fft_grad_W<T, L, NTC, 1>), grid, NTC, col_lds);
+            if (cg == 2) TNMF_FFT_LAUNCH((k_fft_grad_W<T, L, NTC, 2>), grid, NTC, col_lds);
+            TNMF_FFT_LAUNCH((k_fft_grad_W<T, L, NTC, 3>), grid, NTC, col_lds);
+        }
         default: break;
     }
     return TNMF_E_UNSUPPORTED;
