@@ -134,8 +134,6 @@ __global__ __launch_bounds__(NT) void k_fft_rows_fwd(FftArgs a) {
 
 // kFftRowsInv  (MODE 0): src0 row spectra -> dst0 real [planes][rows][ld_dst], columns [xoff, xoff+cols)
 // kFftRowsInv2 (MODE 1): src0, src1 -> dst0, dst1 likewise
-// kFftRowsMu   (MODE 2): src0 = neg, src1 = pos row spectra; dst0 = H real (in/out, ps_src/ld_dst/cols describe it);
-//                        H = (H*neg)/(pos+reg)  (TransformInvariantNMF.py:232-235), then dst1 = row spectra of the new H
 template <typename T, int L, int NB, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_fft_rows_inv(FftArgs a) {
     using P = FftPlanFor<T, L>;
@@ -154,36 +152,16 @@ __global__ __launch_bounds__(NT) void k_fft_rows_inv(FftArgs a) {
     __syncthreads();
     tile_inv<T, P, NB, BS, NT>(x, tw, tid);
     if (MODE != 0) tile_inv<T, P, NB, BS, NT>(xb, tw, tid);
-    T *xr = reinterpret_cast<T *>(x);
-    T *xbr = reinterpret_cast<T *>(xb);
-    if (MODE == 0 || MODE == 1) {
-        T *d0 = static_cast<T *>(a.dst0) + plane * a.ps_dst;
-        T *d1 = MODE == 1 ? static_cast<T *>(a.dst1) + plane * a.ps_dst : nullptr;
-        for (int idx = tid; idx < 2 * NB * a.cols; idx += NT) {
-            const int r = idx / a.cols, xc = idx - r * a.cols, y = y0 + r;
-            if (y >= a.rows) continue;
-            const int off = ((xc + a.xoff) * BS + (r >> 1)) * 2 + (r & 1);
-            d0[(long)y * a.ld_dst + xc] = xr[off];
-            if (MODE == 1) d1[(long)y * a.ld_dst + xc] = xbr[off];
-        }
-    } else {
-        T *Hp = static_cast<T *>(a.dst0) + plane * a.ps_src;
-        const T reg = (T)a.reg;
-        for (int idx = tid; idx < 2 * NB * L; idx += NT) {
-            const int r = idx / L, xx = idx - r * L, y = y0 + r;
-            const int off = (xx * BS + (r >> 1)) * 2 + (r & 1);
-            T hn = 0;
-            if (y < a.rows && xx < a.cols) {
-                const T h = Hp[(long)y * a.ld_dst + xx];
-                hn = (h * xr[off]) / (xbr[off] + reg);
-                Hp[(long)y * a.ld_dst + xx] = hn;
-            }
-            xr[off] = hn;
-        }
-        __syncthreads();
-        tile_fwd<T, P, NB, BS, NT>(x, tw, tid);
-        store_rows_split<T, P, NB, BS, NT>(x, static_cast<cplx<T> *>(a.dst1) + plane * a.ps_dst, y0, a.rows, a.KXP,
-                                           tid);
+    const T *xr = reinterpret_cast<const T *>(x);
+    const T *xbr = reinterpret_cast<const T *>(xb);
+    T *d0 = static_cast<T *>(a.dst0) + plane * a.ps_dst;
+    T *d1 = MODE == 1 ? static_cast<T *>(a.dst1) + plane * a.ps_dst : nullptr;
+    for (int idx = tid; idx < 2 * NB * a.cols; idx += NT) {
+        const int r = idx / a.cols, xc = idx - r * a.cols, y = y0 + r;
+        if (y >= a.rows) continue;
+        const int off = ((xc + a.xoff) * BS + (r >> 1)) * 2 + (r & 1);
+        d0[(long)y * a.ld_dst + xc] = xr[off];
+        if (MODE == 1) d1[(long)y * a.ld_dst + xc] = xbr[off];
     }
 }
 
