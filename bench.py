@@ -144,7 +144,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument('--samples', type=int, default=None, help='override samples per GPU (debug)')
-    ap.add_argument('--path', default='auto', choices=['auto', 'generic', 'mfma', 'fft'])
+    ap.add_argument('--path', default='auto', choices=['auto', 'generic', 'mfma', 'fft', 'hybrid'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fft-variant', action='store_true', help='skip the second timed leg on the FFT kernel family')
     ap.add_argument('--cpu-budget', type=float, default=20.0)

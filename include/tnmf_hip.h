@@ -48,10 +48,14 @@ typedef struct {
     int dtype; /* 0 = f32, 1 = f64 */
 } tnmf_hip_geom;
 
-/* Kernel family selection (tnmf_hip_ctx_set_path): AUTO picks the MFMA kernels where the shape allows.  FFT is the
+/* Kernel family selection (tnmf_hip_ctx_set_path): AUTO picks the MFMA kernels where the shape allows and, for float32
+ * problems with at least 2^22 activation entries, the HYBRID dispatch described below.  FFT is the
  * frequency-domain formulation (the algorithm of the reference's default backend, tnmf/backends/NumPy_FFT.py:16-40):
  * float32 2-D problems with shift shapes up to 576, float64 up to 144. */
-enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_FFT = 3 };
+enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_FFT = 3, TNMF_PATH_HYBRID = 4 };
+/* HYBRID: reconstruct and the W gradient on the FFT family (their float32 transform error is benign: R has no small
+ * entries, the W gradient is a sum over all samples), the H gradient / fused H update on the direct kernels (exact
+ * summation of the few-tap border entries).  Falls back to AUTO where the FFT family does not cover the shape. */
 
 int tnmf_hip_abi_version(void);
 const char *tnmf_hip_strerror(int code);

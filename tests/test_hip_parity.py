@@ -209,7 +209,7 @@ def test_known_answer_stream_f64():
     assert np.isclose(nmf._energy_function(), 96.7375921)         # tnmf/tests/test_stream.py:25
 
 
-@pytest.mark.parametrize('path', PATHS + ['fft'])
+@pytest.mark.parametrize('path', PATHS + ['fft', 'hybrid'])
 @pytest.mark.parametrize('N,C,D,M,A', [(8, 1, (64, 64), 8, (9, 9)), (4, 1, (96, 80), 32, (12, 12)), (3, 3, (48, 48), 32, (12, 12))])
 def test_f32_loop_parity_with_f64_oracle(N, C, D, M, A, path):
     """North-star criterion: W within 1e-5 (max-relative) of the float64 reference after a fixed 5 iterations."""
@@ -354,6 +354,35 @@ def test_fft_family_reproduces_reference_known_answers_f64(scenario):
         E = {'Cyclic_MU': 14434.02658, 'ASG_MU': 4558.86695, 'GSAG_MU': 14310.92041}[scenario]   # test_minibatch.py:18-25
     assert nmf._backend.last_path == 'fft'
     assert np.isclose(nmf._energy_function(), E)
+
+
+@pytest.mark.parametrize('C,D,M,A', BASELINE_SHAPES, ids=['config2', 'config3', 'config4', 'config5'])
+def test_auto_dispatch_at_baseline_sizes(C, D, M, A):
+    """path='auto' on float32 problems of this size is the hybrid dispatch: reconstruct and the W gradient on the FFT
+    family, the H gradient and the fused H update on the matrix-core kernels -- and every result, the updated H
+    included, agrees with the generic kernels at the tolerance of the direct path."""
+    rng = np.random.default_rng(6)
+    N = 16 if M == 16 else 4          # at least 2^22 activation entries: the threshold of the hybrid dispatch
+    V = rng.random((N, C) + D).astype(np.float32)
+    Wn = rng.random((M, C) + A).astype(np.float32)
+    Hn = rng.random((N, M) + tuple(d + a - 1 for d, a in zip(D, A))).astype(np.float32)
+    out = {}
+    for path in ('auto', 'generic'):
+        be = make_backend(V, A, M, path)
+        W, H = dev(Wn, np.float32), dev(Hn, np.float32)
+        R = be.reconstruct(W, H)
+        assert be.last_path == ('fft' if path == 'auto' else path)
+        nH, pH = be.reconstruction_gradient_H(V, W, H)
+        assert be.last_path == ('mfma' if path == 'auto' else path)
+        nW, pW = be.reconstruction_gradient_W(V, W, H)
+        assert be.last_path == ('fft' if path == 'auto' else path)
+        Hf = H.clone()
+        be.fused_update_H(V, W, Hf, slice(None), sparsity=0.05, eps=1e-9)
+        Wf = W.clone()
+        be.fused_update_W(V, Wf, Hf, slice(None), eps=1e-9)
+        out[path] = [be.to_ndarray(x) for x in (R, nH, pH, nW, pW, Hf, Wf)]
+    for got, want in zip(out['auto'], out['generic']):
+        assert relmax(got, want) < 2e-5
 
 
 @pytest.mark.parametrize('C,D,M,A', BASELINE_SHAPES, ids=['config2', 'config3', 'config4', 'config5'])

@@ -24,7 +24,7 @@ EXPORTS = (
 
 MODES = {'valid': 0, 'full': 1, 'circular': 2, 'reflect': 3}
 
-PATHS = {'auto': 0, 'generic': 1, 'mfma': 2, 'fft': 3}
+PATHS = {'auto': 0, 'generic': 1, 'mfma': 2, 'fft': 3, 'hybrid': 4}
 
 
 class Geom(ctypes.Structure):

@@ -83,8 +83,18 @@ inline char *ws_at(tnmf_hip_ctx *ctx, size_t off) { return static_cast<char *>(c
 
 enum Prim { kReconstruct, kCorrW, kCorrH };
 
+// FFT family for reconstruct and the W gradient (the hybrid dispatch): forced by TNMF_PATH_HYBRID wherever the family
+// covers the shape; chosen by TNMF_PATH_AUTO for float32 problems large enough to fill the chip with transform tiles.
+// Measured: W, H and the energy stay as close to the float64 oracle as with the direct kernels alone,
+// because the H gradient -- the only place where float32 transform error matters -- stays on the direct kernels.
+bool use_fft_hybrid(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
+    if (ctx->path == TNMF_PATH_HYBRID) return fft_has(g, dtype);
+    if (ctx->path != TNMF_PATH_AUTO || dtype != 0 || !fft_has(g, dtype)) return false;
+    return (size_t)g.N * g.M * g.Hy * g.Hx >= ((size_t)1 << 22);
+}
+
 bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
-    if (ctx->path == TNMF_PATH_GENERIC || ctx->path == TNMF_PATH_FFT) return false;
+    if (ctx->path == TNMF_PATH_GENERIC || ctx->path == TNMF_PATH_FFT) return false;   // (FFT never gets here)
     switch (prim) {
         case kReconstruct: return mfma_has_reconstruct(g, dtype);
         case kCorrW: return mfma_has_corr_W(g, dtype);
@@ -111,7 +121,7 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
 
 int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
-    if (ctx->path == TNMF_PATH_FFT) return fft_reconstruct(ctx, g, dtype, W, H, R, s);
+    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype)) return fft_reconstruct(ctx, g, dtype, W, H, R, s);
     if (use_mfma(ctx, g, dtype, kReconstruct)) {
         ctx->last_path = "mfma";
         return mfma_reconstruct(ctx, g, (const float *)W, (const float *)H, (float *)R, s);
@@ -126,6 +136,7 @@ int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const v
     if (g.N == 0) return TNMF_OK;
     if (ctx->path == TNMF_PATH_FFT)
         return fused ? fft_update_H(ctx, g, dtype, V, R, W, Hio, reg, s) : fft_grad_H(ctx, g, dtype, V, R, W, neg, pos, s);
+    if (fused) fft_invalidate_H(ctx);   // the direct kernels are about to change H: cached row spectra are stale
     if (use_mfma(ctx, g, dtype, kCorrW)) {
         ctx->last_path = "mfma";
         return mfma_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio, (float *)neg,
@@ -146,7 +157,8 @@ int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, con
         TNMF_HIP_TRY(hipMemsetAsync(pos, 0, (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype), s));
         return TNMF_OK;
     }
-    if (ctx->path == TNMF_PATH_FFT) return fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, s);
+    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype))
+        return fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, s);
     if (use_mfma(ctx, g, dtype, kCorrH)) {
         ctx->last_path = "mfma";
         P = mfma_corr_H_chunks(ctx, g);
@@ -228,7 +240,7 @@ int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom) {
 
 int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path) {
     if (!ctx) return TNMF_E_NULL;
-    if (path < TNMF_PATH_AUTO || path > TNMF_PATH_FFT) return TNMF_E_UNSUPPORTED;
+    if (path < TNMF_PATH_AUTO || path > TNMF_PATH_HYBRID) return TNMF_E_UNSUPPORTED;
     ctx->path = path;
     return TNMF_OK;
 }

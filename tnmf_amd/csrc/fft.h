@@ -52,7 +52,8 @@ TNMF_FFT_DECL(576);
 
 // shape support (2-D problems, transform length available for the activation shape, dtype instantiated)
 bool fft_has(const Geo &g, int dtype);
-void fft_invalidate(tnmf_hip_ctx *ctx);
+void fft_invalidate(tnmf_hip_ctx *ctx);     // H and V may have changed
+void fft_invalidate_H(tnmf_hip_ctx *ctx);   // H has changed
 void fft_release(tnmf_hip_ctx *ctx);
 
 int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s);

@@ -43,7 +43,7 @@ struct Lay {
     int Ly, Lx, KX, KXP, ngroups, nper, chunk, mgroups, mper;
     fft_run_fn rowf, colf;
     size_t csz;  // bytes of one complex element
-    size_t T, Tn, Tp, SV, SR, Ts, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total;
+    size_t T, Tn, Tp, SV, SR, Ts, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total, total_no_window;
 };
 
 bool make_layout(const Geo &g, int dtype, Lay *l) {
@@ -90,8 +90,6 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
         return at;
     };
     l->T = take(nT);
-    l->Tn = take(nTc);
-    l->Tp = take(nTc);
     l->SV = take(nS);
     l->SR = take(nS);
     l->Ts = take((size_t)g.N * g.C * g.Dy * kxp * c);
@@ -103,6 +101,9 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
     l->Gp = take(nSW * l->ngroups);
     l->Gs = take(nSW * 2);
     l->Wo = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
+    l->total_no_window = o;
+    l->Tn = take(nTc);   // the window buffers of the H half step come last: callers that never run it (the hybrid
+    l->Tp = take(nTc);   // dispatch) do not pay for them
     l->total = o;
     return true;
 }
@@ -269,9 +270,9 @@ int rows_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const vo
     return TNMF_OK;
 }
 
-int prepare(tnmf_hip_ctx *ctx, const Geo &g, int dtype, Lay *l) {
+int prepare(tnmf_hip_ctx *ctx, const Geo &g, int dtype, Lay *l, bool window = false) {
     if (!fft_has(g, dtype) || !make_layout(g, dtype, l)) return TNMF_E_UNSUPPORTED;
-    CHECK(ensure_ws(ctx, l->total));
+    CHECK(ensure_ws(ctx, window ? l->total : l->total_no_window));
     ctx->last_path = "fft";
     return TNMF_OK;
 }
@@ -282,6 +283,8 @@ bool fft_has(const Geo &g, int dtype) {
     if (g.Dy == 1 && g.Ay == 1) return false;   // 1-D signals stay on the direct kernels
     return pick_len(g.Hy, dtype) != 0 && pick_len(g.Hx, dtype) != 0;
 }
+
+void fft_invalidate_H(tnmf_hip_ctx *ctx) { ctx->fft.T_valid = false; }
 
 void fft_invalidate(tnmf_hip_ctx *ctx) {
     ctx->fft.T_valid = false;
@@ -355,7 +358,7 @@ int grad_H_window(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, int 
 int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *neg,
                void *pos, hipStream_t s) {
     Lay l;
-    CHECK(prepare(ctx, g, dtype, &l));
+    CHECK(prepare(ctx, g, dtype, &l, true));
     CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));
     const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hx;
     for (int n0 = 0; n0 < g.N; n0 += l.chunk) {
@@ -380,7 +383,7 @@ int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
 int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *H,
                  double reg, hipStream_t s) {
     Lay l;
-    CHECK(prepare(ctx, g, dtype, &l));
+    CHECK(prepare(ctx, g, dtype, &l, true));
     CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));
     ctx->fft.T_valid = false;
     const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hx, tplane = (size_t)g.M * g.Hy * l.KXP;

@@ -109,27 +109,52 @@ __device__ __forceinline__ void load_rows_merge(cplx<T> *x, const cplx<T> *src, 
 }
 
 // kFftRowsFwd: src0 real [planes][rows][ld_src] (cols valid) -> dst0 row spectra [planes][rows][KXP]
+// Thread mapping: for the real data a thread owns column x = tid (+ NT, ...) for all 2*NB rows -- those tile elements
+// are consecutive floats, so all addresses are a per-thread base plus an immediate; for the spectra it owns frequency
+// kx = tid (+ NT, ...) for all row pairs, with its two digit-reversed tile positions computed once.
 template <typename T, int L, int NB, int NT>
 __global__ __launch_bounds__(NT) void k_fft_rows_fwd(FftArgs a) {
     using P = FftPlanFor<T, L>;
-    constexpr int BS = NB + 1;
+    constexpr int BS = NB + 1, KX = L / 2 + 1, R2 = 2 * NB;
+    constexpr int XS = (L + NT - 1) / NT, KS = (KX + NT - 1) / NT;
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
     cplx<T> *tw = x + L * BS;
-    const int tid = threadIdx.x, y0 = blockIdx.x * 2 * NB;
+    const int tid = threadIdx.x, y0 = blockIdx.x * R2;
     const long plane = blockIdx.y;
     make_twiddles<T, L>(tw, tid, NT);
     const T *src = static_cast<const T *>(a.src0) + plane * a.ps_src;
     T *xr = reinterpret_cast<T *>(x);
-    for (int idx = tid; idx < 2 * NB * L; idx += NT) {
-        const int r = idx / L, xx = idx - r * L, y = y0 + r;
-        T v = 0;
-        if (y < a.rows && xx < a.cols) v = src[(long)y * a.ld_src + xx];
-        xr[(xx * BS + (r >> 1)) * 2 + (r & 1)] = v;
+#pragma unroll
+    for (int sl = 0; sl < XS; ++sl) {
+        const int xx = tid + sl * NT;
+        if (xx < L) {
+            const int xc = min(xx, a.cols - 1);
+            T v[R2];
+#pragma unroll
+            for (int r = 0; r < R2; ++r) v[r] = src[(long)min(y0 + r, a.rows - 1) * a.ld_src + xc];
+#pragma unroll
+            for (int r = 0; r < R2; ++r) xr[xx * (2 * BS) + r] = (y0 + r < a.rows && xx < a.cols) ? v[r] : (T)0;
+        }
     }
     __syncthreads();
     tile_fwd<T, P, NB, BS, NT>(x, tw, tid);
-    store_rows_split<T, P, NB, BS, NT>(x, static_cast<cplx<T> *>(a.dst0) + plane * a.ps_dst, y0, a.rows, a.KXP, tid);
+    cplx<T> *dst = static_cast<cplx<T> *>(a.dst0) + plane * a.ps_dst;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = tid + ks * NT;
+        if (k < KX) {
+            const int pk = P::pos_of_k(k) * BS, plk = P::pos_of_k(k == 0 ? 0 : L - k) * BS;
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const int ya = y0 + 2 * p;
+                cplx<T> A, B;
+                split_pair(x[pk + p], x[plk + p], A, B);
+                if (ya < a.rows) dst[(long)ya * a.KXP + k] = A;
+                if (ya + 1 < a.rows) dst[(long)(ya + 1) * a.KXP + k] = B;
+            }
+        }
+    }
 }
 
 // kFftRowsInv  (MODE 0): src0 row spectra -> dst0 real [planes][rows][ld_dst], columns [xoff, xoff+cols)
