@@ -79,13 +79,14 @@ def synth_V_on_device(cfg, n_local, seed, device):
     return out
 
 
-def measured_traffic(kernel_name, cfg_id, path):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), config 3 / MFMA path only."""
+def measured_traffic(kernel_name, cfg_id, family):
+    """HBM bytes per launch of a kernel group from the committed PMC passes (profiles/r01_traffic.json, config 3)."""
     f = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-    if cfg_id != 3 or path != 'mfma' or not os.path.exists(f):
+    if cfg_id != 3 or not os.path.exists(f):
         return None
     try:
-        return json.load(open(f))['kernels'][kernel_name]['traffic_bytes']
+        entry = json.load(open(f))['kernels'][kernel_name]
+        return entry['traffic_bytes'] if entry.get('family', 'mfma') == family else None
     except (KeyError, ValueError):
         return None
 
@@ -146,7 +147,7 @@ def main():
     ap.add_argument('--samples', type=int, default=None, help='override samples per GPU (debug)')
     ap.add_argument('--path', default='auto', choices=['auto', 'generic', 'mfma', 'fft', 'hybrid'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-fft-variant', action='store_true', help='skip the second timed leg on the FFT kernel family')
+    ap.add_argument('--no-fft-variant', action='store_true', help='skip the extra timed legs on the other kernel families')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
 
@@ -192,95 +193,109 @@ def main():
     else:
         V = V_local
 
-    np.random.seed(42)             # same W on every rank
-    torch.cuda.manual_seed(4242 + rank)
-    nmf = TransformInvariantNMF(n_atoms=cfg['M'], atom_shape=tuple(cfg['A']), backend='hip', device=device,
-                                path=args.path, init='device', process_group=group)
-    nmf._initialize_matrices(V, keep_W=False)
+    F = conv_flops(cfg, n_local)
+    Hs = tuple(d + a - 1 for d, a in zip(cfg['D'], cfg['A']))
+    h_bytes = 4.0 * n_local * cfg['M'] * float(np.prod(Hs))
+    t_bytes = 0.0
+    if k == 2:   # row spectra of the FFT family: N*M*Hy*(Lx/2+1) complex64
+        Lx = next((L for L in (32, 48, 64, 96, 144, 192, 288, 384, 576) if L >= Hs[1]), 0)
+        t_bytes = 8.0 * n_local * cfg['M'] * Hs[0] * (Lx // 2 + 1)
+
+    def group_roofline(name, avg_ms, paths):
+        """Roofline entry of one kernel group: matrix-core groups against the f32 MFMA rate with the algorithmic flops of
+        the direct formulation, FFT-family groups against HBM with the streams that formulation must move per launch."""
+        fam = paths.get(name)
+        flops = {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}.get(name)
+        if flops is None or not avg_ms:
+            return None
+        if fam == 'fft':
+            hybrid = paths.get('update_H') != 'fft'     # H changes outside the family: its row spectra are redone
+            streams = {'reconstruct': t_bytes + (0.5 * (h_bytes + t_bytes) if hybrid else 0.0),
+                       'update_H': 5 * t_bytes + 2 * h_bytes, 'grad_W': t_bytes}[name]
+            gbs = streams / (avg_ms * 1e-3) / 1e9
+            return {'kernel': name, 'family': fam, 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': gbs / PEAK_HBM_GBS, 'bytes_per_launch': streams, 'avg_launch_ms': avg_ms,
+                    'direct_equivalent_tflops': flops / (avg_ms * 1e-3) / 1e12}
+        tf = flops / (avg_ms * 1e-3) / 1e12
+        return {'kernel': name, 'family': fam, 'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': tf / PEAK_F32_TFLOPS, 'flops_per_launch': flops, 'avg_launch_ms': avg_ms}
+
+    def run_leg(path, pg):
+        """args.warmup untimed + args.steps timed MU iterations from the fixed start on kernel family `path`."""
+        np.random.seed(42)             # same W on every rank
+        torch.cuda.manual_seed(4242 + rank)
+        model = TransformInvariantNMF(n_atoms=cfg['M'], atom_shape=tuple(cfg['A']), backend='hip', device=device,
+                                      path=path, init='device', process_group=pg)
+        model._initialize_matrices(V, keep_W=False)
+        b = model._backend
+
+        def fence():
+            if pg is not None:
+                dist.barrier()
+            torch.cuda.synchronize(device)
+
+        for _ in range(args.warmup):
+            model._update_H()
+            model._update_W()
+        fence()
+        b.start_timeline()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model._update_H()
+            model._update_W()
+        fence()
+        el = time.perf_counter() - t0
+        paths = b.timeline_paths
+        spans = b.stop_timeline()
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        if pg is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return model, float(t.item()), spans, paths
+
+    nmf, elapsed, spans, paths = run_leg(args.path, group)
     be = nmf._backend
-
-    def step():
-        nmf._update_H()
-        nmf._update_W()
-
-    def fence():
-        if group is not None:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    be.start_timeline()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    spans = be.stop_timeline()
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if group is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
     energy = nmf._energy_function()     # collective when sharded; outside the timed region
 
-    # Second leg (single GPU only): the same iterations from the same start on the FFT kernel family -- the
-    # frequency-domain formulation of the same update (BASELINE.json configs[4]: "FFT-vs-direct crossover").
-    fft_variant = None
-    if world == 1 and args.path != 'fft' and not args.no_fft_variant and k == 2:
-        np.random.seed(42)
-        torch.cuda.manual_seed(4242 + rank)
-        nmf2 = TransformInvariantNMF(n_atoms=cfg['M'], atom_shape=tuple(cfg['A']), backend='hip', device=device,
-                                     path='fft', init='device')
-        nmf2._initialize_matrices(V, keep_W=False)
-        for _ in range(args.warmup):
-            nmf2._update_H()
-            nmf2._update_W()
-        torch.cuda.synchronize(device)
-        nmf2._backend.start_timeline()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            nmf2._update_H()
-            nmf2._update_W()
-        torch.cuda.synchronize(device)
-        el2 = time.perf_counter() - t1
-        spans2 = nmf2._backend.stop_timeline()
-        Wd, Wf = nmf.W, nmf2.W
-        # the formulation's own HBM streams per iteration: row spectra T = N*M*Hy*(Lx/2+1) complex64
-        # read 5x / written 3x, H read and written once, everything else is N*C- or M*C-sized
-        Hy, Hx = (d + a - 1 for d, a in zip(cfg['D'], cfg['A']))
-        Lx = next(L for L in (32, 48, 64, 96, 144, 192, 288, 384, 576) if L >= Hx)
-        t_bytes = n_local * cfg['M'] * Hy * (Lx // 2 + 1) * 8
-        h_bytes = n_local * cfg['M'] * Hy * Hx * 4
-        fft_stream_bytes = 8 * t_bytes + 2 * h_bytes
-        fft_variant = {
-            'value': args.steps / el2, 'unit': 'MU-iterations/sec', 'ms_per_step': el2 / args.steps * 1e3,
-            'kernel_path': nmf2._backend.last_path,
-            'what': "same data, same start, same iteration count on path='fft' (own LDS transforms, fused contractions)",
-            'kernels_ms': {name: float(np.mean(ms)) for name, ms in spans2.items()},
-            'W_max_rel_diff_vs_direct': float(np.abs(Wf - Wd).max() / np.abs(Wd).max()),
-            'energy_after_run': nmf2._energy_function(),
-            'speedup_over_direct': (args.steps / el2) / (world * args.steps / elapsed),
-            'roofline': {'bound': 'hbm', 'achieved': fft_stream_bytes / (el2 / args.steps) / 1e9, 'peak': PEAK_HBM_GBS,
-                         'unit': 'GB/s', 'frac': fft_stream_bytes / (el2 / args.steps) / 1e9 / PEAK_HBM_GBS,
-                         'stream_bytes_per_iteration': fft_stream_bytes,
-                         'what': 'whole iteration: bytes the FFT formulation must stream (8 passes over the row '
-                                 'spectra + H read/write) / iteration time'},
-        }
-        del nmf2
+    # Further legs (single GPU only): the same iterations from the same start on the other kernel families -- the
+    # direct-vs-FFT crossover of BASELINE.json configs[4].
+    variants = {}
+    main_family = 'hybrid' if set(paths.values()) >= {'fft', 'mfma'} else be.last_path
+    if world == 1 and not args.no_fft_variant and k == 2:
+        W_main = nmf.W
+        for vpath, label in (('mfma', 'direct_variant'), ('fft', 'fft_variant')):
+            if vpath == main_family or args.path == vpath:
+                continue
+            try:
+                m2, el2, spans2, paths2 = run_leg(vpath, None)
+            except Exception as exc:  # noqa: BLE001   (family does not cover the shape)
+                variants[label] = {'error': repr(exc)[:200]}
+                continue
+            ms2 = {name: float(np.mean(ms)) for name, ms in spans2.items()}
+            variants[label] = {
+                'value': args.steps / el2, 'unit': 'MU-iterations/sec', 'ms_per_step': el2 / args.steps * 1e3,
+                'path': vpath, 'kernel_families': paths2, 'kernels_ms': ms2,
+                'what': 'same data, same start, same iteration count, every kernel group forced onto this family',
+                'W_max_rel_diff_vs_main': float(np.abs(m2.W - W_main).max() / np.abs(W_main).max()),
+                'energy_after_run': m2._energy_function(),
+                'speed_relative_to_main': (args.steps / el2) / (world * args.steps / elapsed),
+                'roofline': [r for r in (group_roofline(nm, ms2.get(nm), paths2) for nm in ('reconstruct', 'update_H', 'grad_W')) if r],
+            }
+            del m2
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        F = conv_flops(cfg, n_local)
-        flops_per_launch = {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}
         kernels = {}
         for name, ms in spans.items():
-            kernels[name] = {'launches': len(ms), 'avg_ms': float(np.mean(ms)), 'total_ms': float(np.sum(ms))}
-            if name in flops_per_launch:
-                kernels[name]['tflops'] = flops_per_launch[name] / (np.mean(ms) * 1e-3) / 1e12
-        dom = max((n for n in kernels if n in flops_per_launch), key=lambda n: kernels[n]['total_ms'])
-        achieved = kernels[dom]['tflops']
+            kernels[name] = {'launches': len(ms), 'avg_ms': float(np.mean(ms)), 'total_ms': float(np.sum(ms)),
+                             'family': paths.get(name)}
+        rl = {name: group_roofline(name, kernels[name]['avg_ms'], paths) for name in kernels}
+        rl = {n: r for n, r in rl.items() if r}
+        for n, r in rl.items():
+            kernels[n]['tflops_direct_equivalent'] = {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}[n] / (kernels[n]['avg_ms'] * 1e-3) / 1e12
+        dom = max(rl, key=lambda n: kernels[n]['total_ms'])
         ms_per_step = elapsed / args.steps * 1e3
+        roof = dict(rl[dom])
+        roof['traffic'] = measured_traffic(dom, args.config, paths.get(dom)) if not args.samples else None
         line = {
             'metric': 'MU-iterations/sec', 'value': world * args.steps / elapsed, 'unit': 'MU-iterations/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -289,7 +304,8 @@ def main():
                 'workload': f'2-D shift-invariant MU, full batch: {n_local} samples x {cfg["C"]} ch x '
                             f'{"x".join(map(str, cfg["D"]))} per GPU, {cfg["M"]} atoms '
                             f'{"x".join(map(str, cfg["A"]))} (BASELINE.json configs[{args.config - 1}])',
-                'samples_per_gpu': n_local, 'global_samples': n_global, 'kernel_path': be.last_path,
+                'samples_per_gpu': n_local, 'global_samples': n_global, 'path': args.path, 'kernel_path': main_family,
+                'kernel_families': paths,
                 'parallelism': f'sample-sharded x{world}, all-reduce of W num/den per iteration' if world > 1 else 'single GPU',
                 'value_definition': 'shard-iterations completed by all ranks / max-over-ranks wall time',
                 'energy_after_run': energy,
@@ -301,15 +317,10 @@ def main():
                 'frac_hbm_peak': alg_bytes(cfg, n_local) / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
             'kernels': kernels,
-            'roofline': {
-                'kernel': dom, 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / PEAK_F32_TFLOPS,
-                'traffic': measured_traffic(dom, args.config, be.last_path) if not args.samples else None,
-                'flops_per_launch': flops_per_launch[dom], 'avg_launch_ms': kernels[dom]['avg_ms'],
-            },
+            'roofline': roof,
+            'roofline_by_kernel': rl,
         }
-        if fft_variant is not None:
-            line['fft_variant'] = fft_variant
+        line.update(variants)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_budget)
             line['cpu_baseline']['gpu_over_cpu'] = line['value'] / line['cpu_baseline']['value']

@@ -42,6 +42,7 @@ class _EventSpan:
         if self.backend._timeline is not None:
             self.e1.record(torch.cuda.current_stream(self.backend._device))
             self.backend._timeline.append((self.name, self.e0, self.e1))
+            self.backend._timeline_paths[self.name] = self.backend.last_path
         return False
 
 
@@ -102,6 +103,7 @@ class HIP_Backend(Backend):
         self._R_scratch = None
         self._negpos = None
         self._timeline = None
+        self._timeline_paths = {}
 
     def __del__(self):
         try:
@@ -137,6 +139,12 @@ class HIP_Backend(Backend):
         """From now on the fused half steps launch their reconstruct separately and bracket every kernel group with
         HIP events (recorded on the launch stream, no host synchronisation)."""
         self._timeline = []
+        self._timeline_paths = {}
+
+    @property
+    def timeline_paths(self):
+        """{kernel group: kernel family it ran on} of the last timeline."""
+        return dict(self._timeline_paths)
 
     def stop_timeline(self):
         """-> {name: [milliseconds per launch, ...]}; synchronises."""
