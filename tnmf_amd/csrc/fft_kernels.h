@@ -24,6 +24,7 @@ struct LenCfg {
     static constexpr int row_pairs = L > 288 ? 8 : 16;
     static constexpr int row_threads = 256;
     static constexpr int mu_pairs = L > 288 ? 4 : 8;   // the fused update kernel keeps its tile small: more blocks per CU
+    static constexpr int mu_threads = L / 2 + 1 > 256 ? 512 : 256;
     // channels per pass of the contraction kernels (accumulators live in registers)
 };
 
@@ -192,93 +193,151 @@ __global__ __launch_bounds__(NT) void k_fft_rows_inv(FftArgs a) {
 
 // kFftRowsMu: src0 = neg, src1 = pos row spectra; dst0 = H real (in/out; ps_src / ld_dst / cols describe it);
 //   H = (H*neg)/(pos+reg)  (TransformInvariantNMF.py:232-235), then dst1 = row spectra of the new H.
-// One LDS tile is used three times (neg, pos, new H): the neg values, the pos spectra and the H values a thread needs
-// are staged in registers, loaded before the first transform so that their latency hides behind it.
+// One LDS tile is used three times (neg, pos, new H).  Thread mapping: in the spectrum phases thread t owns the
+// frequency kx = t for all row pairs (its two digit-reversed tile positions are computed once); in the real phases it
+// owns the column x = t for all 2*NB rows, whose tile elements are consecutive floats, so every LDS and global
+// address is a per-thread base plus a compile-time offset -- these phases used to cost more issue slots than the
+// transforms.  The pos spectra and the H values are loaded before the first transform and wait in registers; columns
+// beyond the block size (x >= NT) park their neg values in a small LDS stash instead.
 template <typename T, int L, int NB, int NT>
 __global__ __launch_bounds__(NT) void k_fft_rows_mu(FftArgs a) {
     using P = FftPlanFor<T, L>;
-    constexpr int BS = NB + 1, KX = L / 2 + 1;
-    constexpr int RE = (2 * NB * L + NT - 1) / NT;     // real tile elements per thread
-    constexpr int SE = (NB * KX + NT - 1) / NT;         // (pair, kx) spectrum elements per thread
+    constexpr int BS = NB + 1, KX = L / 2 + 1, R2 = 2 * NB;
+    constexpr int XS = (L + NT - 1) / NT;             // column slots per thread (slot 0 in registers)
+    constexpr int KS = (KX + NT - 1) / NT;            // frequency slots per thread
+    static_assert(KS == 1, "block size must cover Lx/2+1 frequencies");
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
     cplx<T> *tw = x + L * BS;
-    const int tid = threadIdx.x, y0 = blockIdx.x * 2 * NB;
+    T *stash = reinterpret_cast<T *>(tw + L);         // [(x - NT)][2*NB] neg values of the columns x >= NT
+    T *xr = reinterpret_cast<T *>(x);
+    const int tid = threadIdx.x, y0 = blockIdx.x * R2;
     const long plane = blockIdx.y;
     make_twiddles<T, L>(tw, tid, NT);
     const long tin = plane * ((long)a.rows * a.KXP);
+    const cplx<T> *sn = static_cast<const cplx<T> *>(a.src0) + tin;
     const cplx<T> *sp = static_cast<const cplx<T> *>(a.src1) + tin;
     T *Hp = static_cast<T *>(a.dst0) + plane * a.ps_src;
-    // unconditional loads on clamped addresses (masked when used)
-    cplx<T> pa[SE], pb[SE];
+    const int k = tid < KX ? tid : KX - 1;            // frequency of this thread (threads >= KX idle in those phases)
+    const bool kact = tid < KX;
+    const int pk = P::pos_of_k(k) * BS, plk = P::pos_of_k(k == 0 ? 0 : L - k) * BS;
+    const bool kself = (k == 0 || 2 * k == L);
+    // neg spectra first, then pos spectra and H: unconditional loads on clamped addresses, masked at use; the neg
+    // values are consumed right away, the others stay in flight under the first transform
+    cplx<T> na[NB], nb[NB], pa[NB], pb[NB];
 #pragma unroll
-    for (int e = 0; e < SE; ++e) {
-        int idx = tid + e * NT;
-        idx = idx < NB * KX ? idx : NB * KX - 1;
-        const int pr = idx / KX, k = idx - pr * KX;
-        const int ya = min(y0 + 2 * pr, a.rows - 1), yb = min(y0 + 2 * pr + 1, a.rows - 1);
-        pa[e] = sp[(long)ya * a.KXP + k];
-        pb[e] = sp[(long)yb * a.KXP + k];
+    for (int p = 0; p < NB; ++p) {
+        na[p] = sn[(long)min(y0 + 2 * p, a.rows - 1) * a.KXP + k];
+        nb[p] = sn[(long)min(y0 + 2 * p + 1, a.rows - 1) * a.KXP + k];
     }
-    T hv[RE];
 #pragma unroll
-    for (int e = 0; e < RE; ++e) {
-        int idx = tid + e * NT;
-        idx = idx < 2 * NB * L ? idx : 2 * NB * L - 1;
-        const int r = idx / L, xx = idx - r * L;
-        hv[e] = Hp[(long)min(y0 + r, a.rows - 1) * a.ld_dst + min(xx, a.cols - 1)];
+    for (int p = 0; p < NB; ++p) {
+        pa[p] = sp[(long)min(y0 + 2 * p, a.rows - 1) * a.KXP + k];
+        pb[p] = sp[(long)min(y0 + 2 * p + 1, a.rows - 1) * a.KXP + k];
     }
-    load_rows_merge<T, P, NB, BS, NT>(x, static_cast<const cplx<T> *>(a.src0) + tin, y0, a.rows, a.KXP, tid);
-    __syncthreads();
-    tile_inv<T, P, NB, BS, NT>(x, tw, tid);
-    T *xr = reinterpret_cast<T *>(x);
-    T ng[RE];
+    const int xc = min(tid, a.cols - 1);
+    T hv[R2];
 #pragma unroll
-    for (int e = 0; e < RE; ++e) {
-        int idx = tid + e * NT;
-        idx = idx < 2 * NB * L ? idx : 2 * NB * L - 1;
-        const int r = idx / L, xx = idx - r * L;
-        ng[e] = xr[(xx * BS + (r >> 1)) * 2 + (r & 1)];
-    }
-    __syncthreads();
+    for (int r = 0; r < R2; ++r) hv[r] = Hp[(long)min(y0 + r, a.rows - 1) * a.ld_dst + xc];
+    // neg spectra -> tile
+    if (kact) {
 #pragma unroll
-    for (int e = 0; e < SE; ++e) {
-        const int idx = tid + e * NT;
-        if (idx < NB * KX) {
-            const int pr = idx / KX, k = idx - pr * KX, ya = y0 + 2 * pr;
-            cplx<T> A = pa[e], B = pb[e];
+        for (int p = 0; p < NB; ++p) {
+            const int ya = y0 + 2 * p;
+            cplx<T> A = na[p], B = nb[p];
             if (ya >= a.rows) A = {0, 0};
             if (ya + 1 >= a.rows) B = {0, 0};
-            if (k == 0 || 2 * k == L) {
-                x[P::pos_of_k(k) * BS + pr] = {A.x, B.x};
+            if (kself) {
+                x[pk + p] = {A.x, B.x};
             } else {
                 cplx<T> zk, zlk;
                 merge_pair(A, B, zk, zlk);
-                x[P::pos_of_k(k) * BS + pr] = zk;
-                x[P::pos_of_k(L - k) * BS + pr] = zlk;
+                x[pk + p] = zk;
+                x[plk + p] = zlk;
             }
         }
     }
     __syncthreads();
     tile_inv<T, P, NB, BS, NT>(x, tw, tid);
-    const T reg = (T)a.reg;
+    // neg values of this thread's column(s): tile element (x, row r) is the float xr[x * 2*BS + r]
+    T ng[R2];
+    if (tid < L) {
 #pragma unroll
-    for (int e = 0; e < RE; ++e) {
-        const int idx = tid + e * NT;
-        if (idx < 2 * NB * L) {
-            const int r = idx / L, xx = idx - r * L, y = y0 + r;
-            const int off = (xx * BS + (r >> 1)) * 2 + (r & 1);
+        for (int r = 0; r < R2; ++r) ng[r] = xr[tid * (2 * BS) + r];
+    }
+#pragma unroll
+    for (int sl = 1; sl < XS; ++sl) {
+        const int xx = tid + sl * NT;
+        if (xx < L) {
+#pragma unroll
+            for (int r = 0; r < R2; ++r) stash[(xx - NT) * R2 + r] = xr[xx * (2 * BS) + r];
+        }
+    }
+    __syncthreads();
+    // pos spectra -> tile
+    if (kact) {
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int ya = y0 + 2 * p;
+            cplx<T> A = pa[p], B = pb[p];
+            if (ya >= a.rows) A = {0, 0};
+            if (ya + 1 >= a.rows) B = {0, 0};
+            if (kself) {
+                x[pk + p] = {A.x, B.x};
+            } else {
+                cplx<T> zk, zlk;
+                merge_pair(A, B, zk, zlk);
+                x[pk + p] = zk;
+                x[plk + p] = zlk;
+            }
+        }
+    }
+    __syncthreads();
+    tile_inv<T, P, NB, BS, NT>(x, tw, tid);
+    // multiplicative update in place; the new H goes back into the tile (zero outside the data)
+    const T reg = (T)a.reg;
+    if (tid < L) {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const int y = y0 + r, off = tid * (2 * BS) + r;
             T hn = 0;
-            if (y < a.rows && xx < a.cols) {
-                hn = (hv[e] * ng[e]) / (xr[off] + reg);
-                Hp[(long)y * a.ld_dst + xx] = hn;
+            if (y < a.rows && tid < a.cols) {
+                hn = (hv[r] * ng[r]) / (xr[off] + reg);
+                Hp[(long)y * a.ld_dst + tid] = hn;
             }
             xr[off] = hn;
         }
     }
+#pragma unroll
+    for (int sl = 1; sl < XS; ++sl) {
+        const int xx = tid + sl * NT;
+        if (xx < L) {
+#pragma unroll
+            for (int r = 0; r < R2; ++r) {
+                const int y = y0 + r, off = xx * (2 * BS) + r;
+                T hn = 0;
+                if (y < a.rows && xx < a.cols) {
+                    hn = (Hp[(long)y * a.ld_dst + xx] * stash[(xx - NT) * R2 + r]) / (xr[off] + reg);
+                    Hp[(long)y * a.ld_dst + xx] = hn;
+                }
+                xr[off] = hn;
+            }
+        }
+    }
     __syncthreads();
     tile_fwd<T, P, NB, BS, NT>(x, tw, tid);
-    store_rows_split<T, P, NB, BS, NT>(x, static_cast<cplx<T> *>(a.dst1) + plane * a.ps_dst, y0, a.rows, a.KXP, tid);
+    // row spectra of the new H
+    if (kact) {
+        cplx<T> *dst = static_cast<cplx<T> *>(a.dst1) + plane * a.ps_dst;
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int ya = y0 + 2 * p;
+            cplx<T> A, B;
+            split_pair(x[pk + p], x[plk + p], A, B);
+            if (ya < a.rows) dst[(long)ya * a.KXP + k] = A;
+            if (ya + 1 < a.rows) dst[(long)(ya + 1) * a.KXP + k] = B;
+        }
+    }
 }
 
 // ---- column kernels ---------------------------------------------------------------------------------------------
@@ -630,7 +689,10 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
         case kFftRowsMu: {
             constexpr int NBM = Cfg::mu_pairs;
             const dim3 mgrid((unsigned)cdiv(a->rows, 2 * NBM), (unsigned)a->planes);
-            TNMF_FFT_LAUNCH((k_fft_rows_mu<T, L, NBM, NTR>), mgrid, NTR, (size_t)L * (NBM + 1) * sizeof(cplx<T>) + tw_bytes);
+            constexpr int NTM = Cfg::mu_threads;
+            constexpr size_t stash = L > NTM ? (size_t)(L - NTM) * 2 * NBM * sizeof(T) : 0;
+            TNMF_FFT_LAUNCH((k_fft_rows_mu<T, L, NBM, NTM>), mgrid, NTM,
+                            (size_t)L * (NBM + 1) * sizeof(cplx<T>) + tw_bytes + stash);
         }
         case kFftColsFwd:
             TNMF_FFT_LAUNCH((k_fft_cols_fwd<T, L, NTC>), dim3(tiles, (unsigned)a->planes), NTC, col_lds);
