@@ -55,7 +55,9 @@ typedef struct {
 enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_FFT = 3, TNMF_PATH_HYBRID = 4 };
 /* HYBRID: reconstruct and the W gradient on the FFT family (their float32 transform error is benign: R has no small
  * entries, the W gradient is a sum over all samples), the H gradient / fused H update on the direct kernels (exact
- * summation of the few-tap border entries).  Falls back to AUTO where the FFT family does not cover the shape. */
+ * summation of the few-tap border entries).  Falls back to AUTO where the FFT family does not cover the shape.
+ * Under this dispatch reconstruct assumes non-negative factors: it clamps R at zero from below, which only removes
+ * transform rounding noise (W, H >= 0 imply R >= 0) and keeps the denominator of the H update non-negative. */
 
 int tnmf_hip_abi_version(void);
 const char *tnmf_hip_strerror(int code);

@@ -21,6 +21,7 @@ struct FftArgs {
     int N, M, C, Hy;         // contraction kernels
     int n0, ngroups, nper;   // sample window / split of the sample sum
     int mgroups, mper;       // split of the atom loop of the H-gradient kernel over blocks
+    int clamp0;              // plain inverse row kernel: clamp the output at zero from below
     double reg;              // eps (+ sparsity) of the fused update
 };
 
@@ -56,7 +57,10 @@ void fft_invalidate(tnmf_hip_ctx *ctx);     // H and V may have changed
 void fft_invalidate_H(tnmf_hip_ctx *ctx);   // H has changed
 void fft_release(tnmf_hip_ctx *ctx);
 
-int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s);
+// nonneg: clamp R at zero from below (W, H >= 0 make R >= 0; this removes transform rounding noise below zero so
+// that the direct H-gradient kernel keeps its invariant pos >= 0 -- used by the hybrid dispatch)
+int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, bool nonneg,
+                    hipStream_t s);
 // neg/pos of the H gradient from V and a given R
 int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *neg,
                void *pos, hipStream_t s);
@@ -64,5 +68,6 @@ int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
 int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *H,
                  double reg, hipStream_t s);
 // neg/pos of the W gradient (reference orientation) from V, a given R and H
+// nonneg: clamp neg/pos at zero from below (sums of non-negative products: removes transform rounding noise)
 int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *H, void *neg,
-               void *pos, hipStream_t s);
+               void *pos, bool nonneg, hipStream_t s);

@@ -163,11 +163,13 @@ __global__ void k_fft_sum_groups(const cplx<T> *parts, cplx<T> *out, long count,
 
 // neg/pos[m,c,a] = corr[m,c,A-1-a]  (the flip of NumPy.py:85,90)
 template <typename T>
-__global__ void k_fft_flip_out(const T *in, T *out, int planes, int Ay, int Ax) {
+__global__ void k_fft_flip_out(const T *in, T *out, int planes, int Ay, int Ax, int clamp0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, per = Ay * Ax;
     if (i >= planes * per) return;
     const int p = i / per, r = i - p * per, ay = r / Ax, ax = r - ay * Ax;
-    out[i] = in[(long)p * per + (Ay - 1 - ay) * Ax + (Ax - 1 - ax)];
+    T v = in[(long)p * per + (Ay - 1 - ay) * Ax + (Ax - 1 - ax)];
+    if (clamp0) v = v < (T)0 ? (T)0 : v;
+    out[i] = v;
 }
 
 FftArgs base_args(const Geo &g, const Lay &l) {
@@ -299,7 +301,8 @@ void fft_release(tnmf_hip_ctx *ctx) {
     ctx->fft.V_valid = false;
 }
 
-int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
+int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, bool nonneg,
+                    hipStream_t s) {
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l));
     CHECK(spectra_W(ctx, g, l, dtype, W, true, false, s));
@@ -325,6 +328,7 @@ int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, c
     c.xoff = g.Ax - 1;
     c.ld_dst = g.Dx;
     c.ps_dst = (long)g.Dy * g.Dx;
+    c.clamp0 = nonneg ? 1 : 0;
     return l.rowf(kFftRowsInv, dtype, &c, s);
 }
 
@@ -409,7 +413,7 @@ int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, cons
 }
 
 int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *H, void *neg,
-               void *pos, hipStream_t s) {
+               void *pos, bool nonneg, hipStream_t s) {
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l));
     CHECK(rows_of_H(ctx, g, l, dtype, H, s));
@@ -461,14 +465,14 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
     const char *wo = at(ctx, l.Wo);
     if (dtype == 0) {
         hipLaunchKernelGGL(k_fft_flip_out<float>, dim3(cdiv(per, 256)), dim3(256), 0, s, (const float *)wo,
-                           (float *)neg, g.M * g.C, g.Ay, g.Ax);
+                           (float *)neg, g.M * g.C, g.Ay, g.Ax, nonneg ? 1 : 0);
         hipLaunchKernelGGL(k_fft_flip_out<float>, dim3(cdiv(per, 256)), dim3(256), 0, s, (const float *)wo + per,
-                           (float *)pos, g.M * g.C, g.Ay, g.Ax);
+                           (float *)pos, g.M * g.C, g.Ay, g.Ax, nonneg ? 1 : 0);
     } else {
         hipLaunchKernelGGL(k_fft_flip_out<double>, dim3(cdiv(per, 256)), dim3(256), 0, s, (const double *)wo,
-                           (double *)neg, g.M * g.C, g.Ay, g.Ax);
+                           (double *)neg, g.M * g.C, g.Ay, g.Ax, nonneg ? 1 : 0);
         hipLaunchKernelGGL(k_fft_flip_out<double>, dim3(cdiv(per, 256)), dim3(256), 0, s, (const double *)wo + per,
-                           (double *)pos, g.M * g.C, g.Ay, g.Ax);
+                           (double *)pos, g.M * g.C, g.Ay, g.Ax, nonneg ? 1 : 0);
     }
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;

@@ -186,7 +186,9 @@ __global__ __launch_bounds__(NT) void k_fft_rows_inv(FftArgs a) {
         const int r = idx / a.cols, xc = idx - r * a.cols, y = y0 + r;
         if (y >= a.rows) continue;
         const int off = ((xc + a.xoff) * BS + (r >> 1)) * 2 + (r & 1);
-        d0[(long)y * a.ld_dst + xc] = xr[off];
+        T v = xr[off];
+        if (MODE == 0 && a.clamp0) v = v < (T)0 ? (T)0 : v;
+        d0[(long)y * a.ld_dst + xc] = v;
         if (MODE == 1) d1[(long)y * a.ld_dst + xc] = xbr[off];
     }
 }
