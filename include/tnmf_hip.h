@@ -56,8 +56,9 @@ enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_
 /* HYBRID: reconstruct and the W gradient on the FFT family (their float32 transform error is benign: R has no small
  * entries, the W gradient is a sum over all samples), the H gradient / fused H update on the direct kernels (exact
  * summation of the few-tap border entries).  Falls back to AUTO where the FFT family does not cover the shape.
- * Under this dispatch reconstruct assumes non-negative factors: it clamps R at zero from below, which only removes
- * transform rounding noise (W, H >= 0 imply R >= 0) and keeps the denominator of the H update non-negative. */
+ * The FFT family (under FFT and HYBRID alike) assumes non-negative factors: R and the W gradient are clamped at zero
+ * from below, which only removes transform rounding noise (V, W, H >= 0 imply both >= 0) and keeps the denominators
+ * of the multiplicative updates non-negative. */
 
 int tnmf_hip_abi_version(void);
 const char *tnmf_hip_strerror(int code);

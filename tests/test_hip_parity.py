@@ -356,6 +356,40 @@ def test_fft_family_reproduces_reference_known_answers_f64(scenario):
     assert np.isclose(nmf._energy_function(), E)
 
 
+def test_kernel_families_agree_over_a_long_run_with_empty_regions():
+    """120 float32 iterations on a sparse planted model with an exactly blank band (V == 0: both gradients vanish there,
+    the hard case for a float32 frequency-domain update): the hybrid default and the pure FFT family must stay finite
+    and non-negative, drive H to zero in the band and follow the energy trajectory of the direct kernels."""
+    N, C, D, M, A = 16, 1, (128, 128), 16, (9, 9)
+    rng = np.random.default_rng(3)
+    Hs = tuple(d + a - 1 for d, a in zip(D, A))
+    Wt = rng.random((M, C) + A)
+    Wt /= Wt.sum(axis=(-1, -2), keepdims=True)
+    Ht = rng.random((N, M) + Hs) * (rng.random((N, M) + Hs) < 0.002)
+    V = orc.reconstruct(Wt, Ht, 'c')
+    V[:, :, :40, :] = 0
+    V = V.astype(np.float32)
+    runs = {}
+    for path in ('mfma', 'auto', 'fft'):
+        np.random.seed(42)
+        nmf = TransformInvariantNMF(n_atoms=M, atom_shape=A, backend='hip', path=path)
+        nmf._initialize_matrices(V, keep_W=False)
+        E = []
+        for it in range(120):
+            nmf._update_H()
+            nmf._update_W()
+            if it in (9, 59, 119):
+                E.append(nmf._energy_function())
+        runs[path] = (np.array(E), nmf.W, nmf.H)
+    for path in ('auto', 'fft'):
+        E, W, H = runs[path]
+        assert np.all(np.isfinite(E)) and np.all(np.isfinite(W)) and np.all(np.isfinite(H))
+        assert H.min() >= 0 and W.min() >= 0
+        assert np.mean(H[:, :, :30, :] == 0) > 0.999
+        np.testing.assert_allclose(E, runs['mfma'][0], rtol=1e-4)
+        assert relmax(W, runs['mfma'][1]) < 1e-4
+
+
 @pytest.mark.parametrize('C,D,M,A', BASELINE_SHAPES, ids=['config2', 'config3', 'config4', 'config5'])
 def test_auto_dispatch_at_baseline_sizes(C, D, M, A):
     """path='auto' on float32 problems of this size is the hybrid dispatch: reconstruct and the W gradient on the FFT

@@ -121,8 +121,8 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
 
 int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
-    if (ctx->path == TNMF_PATH_FFT) return fft_reconstruct(ctx, g, dtype, W, H, R, false, s);
-    if (use_fft_hybrid(ctx, g, dtype)) return fft_reconstruct(ctx, g, dtype, W, H, R, true, s);
+    // the FFT family serves non-negative factorisations: outputs that are non-negative by construction are clamped
+    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype)) return fft_reconstruct(ctx, g, dtype, W, H, R, true, s);
     if (use_mfma(ctx, g, dtype, kReconstruct)) {
         ctx->last_path = "mfma";
         return mfma_reconstruct(ctx, g, (const float *)W, (const float *)H, (float *)R, s);
@@ -158,8 +158,8 @@ int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, con
         TNMF_HIP_TRY(hipMemsetAsync(pos, 0, (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype), s));
         return TNMF_OK;
     }
-    if (ctx->path == TNMF_PATH_FFT) return fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, false, s);
-    if (use_fft_hybrid(ctx, g, dtype)) return fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, true, s);
+    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype))
+        return fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, true, s);
     if (use_mfma(ctx, g, dtype, kCorrH)) {
         ctx->last_path = "mfma";
         P = mfma_corr_H_chunks(ctx, g);

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(NT) void k_fft_rows_mu(FftArgs a) {
             const int y = y0 + r, off = tid * (2 * BS) + r;
             T hn = 0;
             if (y < a.rows && tid < a.cols) {
-                hn = (hv[r] * ng[r]) / (xr[off] + reg);
+                // both gradients are sums of non-negative products: what is below zero is transform rounding noise
+                hn = (hv[r] * fmax(ng[r], (T)0)) / (fmax(xr[off], (T)0) + reg);
                 Hp[(long)y * a.ld_dst + tid] = hn;
             }
             xr[off] = hn;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(NT) void k_fft_rows_mu(FftArgs a) {
                 const int y = y0 + r, off = xx * (2 * BS) + r;
                 T hn = 0;
                 if (y < a.rows && xx < a.cols) {
-                    hn = (Hp[(long)y * a.ld_dst + xx] * stash[(xx - NT) * R2 + r]) / (xr[off] + reg);
+                    hn = (Hp[(long)y * a.ld_dst + xx] * fmax(stash[(xx - NT) * R2 + r], (T)0)) / (fmax(xr[off], (T)0) + reg);
                     Hp[(long)y * a.ld_dst + xx] = hn;
                 }
                 xr[off] = hn;
