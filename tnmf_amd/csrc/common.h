@@ -25,7 +25,8 @@ struct FftState {
     const void *T_owner;
     Geo T_geo;
     int T_dtype;
-    bool V_valid;            // ... and the full spectra of the samples V_owner (same geometry rules)
+    bool V_valid;            // ... and the row spectra of the samples V_owner (same geometry rules)
+    bool SV_valid;           // ... and their full spectra as well
     const void *V_owner;
     Geo V_geo;
     int V_dtype;

@@ -8,6 +8,7 @@
 //   W gradient   neg[a] = c[A-1-a],  c = crop_[0, A) ( ifft( sum_n H^ conj(V^) ) )     NumPy.py:69-91
 // pos is the same with R in place of V.  1/(Ly*Lx) is folded into the W spectra (and into the partial-sum kernel of
 // the W gradient), so no separate scaling pass exists.
+#include <algorithm>
 #include <cstdlib>
 
 #include "fft.h"
@@ -43,7 +44,7 @@ struct Lay {
     int Ly, Lx, KX, KXP, ngroups, nper, chunk, mgroups, mper;
     fft_run_fn rowf, colf;
     size_t csz;  // bytes of one complex element
-    size_t T, Tn, Tp, SV, SR, Ts, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total, total_no_window;
+    size_t T, Tn, Tp, SV, SR, Ts, VT, RT, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total, total_no_window;
 };
 
 bool make_layout(const Geo &g, int dtype, Lay *l) {
@@ -93,12 +94,17 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
     l->SV = take(nS);
     l->SR = take(nS);
     l->Ts = take((size_t)g.N * g.C * g.Dy * kxp * c);
+    l->VT = take((size_t)g.N * g.C * g.Dy * kxp * c);   // row spectra of V (kept) and of R
+    l->RT = take((size_t)g.N * g.C * g.Dy * kxp * c);
     l->SW = take(nSW);
     l->SWf = take(nSW);
     l->TW = take((size_t)2 * g.M * g.C * g.Ay * kxp * c);
     l->Wt = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
-    l->Gn = take(nSW * l->ngroups);
-    l->Gp = take(nSW * l->ngroups);
+    // partial W-gradient spectra: [groups][M*C][Ly][KXP] for the column-transform kernel, [<= 32 groups][M*C][Ay][KXP]
+    // for the mixed kernel
+    const size_t nG = std::max(nSW * l->ngroups, (size_t)32 * g.M * g.C * g.Ay * kxp * c);
+    l->Gn = take(nG);
+    l->Gp = take(nG);
     l->Gs = take(nSW * 2);
     l->Wo = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
     l->total_no_window = o;
@@ -118,7 +124,7 @@ int ensure_ws(tnmf_hip_ctx *ctx, size_t bytes) {
         f.ws_bytes = 0;
     }
     f.T_valid = false;
-    f.V_valid = false;
+    f.V_valid = f.SV_valid = false;
     const size_t want = align_up(bytes, 1 << 20);
     if (hipMalloc(&f.ws, want) != hipSuccess) {
         (void)hipGetLastError();
@@ -204,6 +210,26 @@ int forward_planes(const Geo &g, const Lay &l, int dtype, const void *src, int p
     return l.colf(kFftColsFwd, dtype, &b, s);
 }
 
+bool use_mixed(const Geo &g, int dtype) {
+    static const bool off = getenv("TNMF_FFT_NO_MIXED") != nullptr;   // diagnostic: force the column-transform kernels
+    return !off && mixed_has(g, dtype);
+}
+
+// Wt <- scale * W (and its flipped copy behind it)
+int scaled_W(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *W, double scale, hipStream_t s) {
+    const int planes = g.M * g.C, n = planes * g.Ay * g.Ax;
+    char *wt = at(ctx, l.Wt);
+    const size_t half = (size_t)n * (l.csz / 2);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_fft_prep_W<float>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float *)W, (float *)wt,
+                           (float *)(wt + half), planes, g.Ay, g.Ax, scale);
+    else
+        hipLaunchKernelGGL(k_fft_prep_W<double>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const double *)W, (double *)wt,
+                           (double *)(wt + half), planes, g.Ay, g.Ax, scale);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
 // W spectra (plain into SW, flipped into SWf), both scaled by 1/(Ly*Lx)
 int spectra_W(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *W, bool plain, bool flipped,
               hipStream_t s) {
@@ -242,16 +268,47 @@ bool same_geo(const Geo &a, const Geo &b) {
     return a.N == b.N && a.M == b.M && a.C == b.C && a.Dy == b.Dy && a.Dx == b.Dx && a.Ay == b.Ay && a.Ax == b.Ax;
 }
 
-// full spectra of the samples into SV (skipped when the cache holds them: V never changes during a fit)
-int spectra_V(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, hipStream_t s) {
+// rows only: real planes [planes][rows][cols] -> row spectra
+int forward_rows(const Geo &g, const Lay &l, int dtype, const void *src, int planes, int rows, int cols, void *Tdst,
+                 hipStream_t s) {
+    FftArgs a = base_args(g, l);
+    a.src0 = src;
+    a.dst0 = Tdst;
+    a.planes = planes;
+    a.rows = rows;
+    a.cols = cols;
+    a.ld_src = cols;
+    a.ps_src = (long)rows * cols;
+    a.ps_dst = (long)rows * l.KXP;
+    return l.rowf(kFftRowsFwd, dtype, &a, s);
+}
+
+int columns_of(const Geo &g, const Lay &l, int dtype, const void *Tsrc, int planes, int rows, void *S, hipStream_t s) {
+    FftArgs b = base_args(g, l);
+    b.src0 = Tsrc;
+    b.dst0 = S;
+    b.planes = planes;
+    b.rows = rows;
+    return l.colf(kFftColsFwd, dtype, &b, s);
+}
+
+// spectra of the samples: row spectra into VT always, full spectra into SV on demand (both skipped when the cache
+// holds them: V never changes during a fit)
+int spectra_V(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, bool full, hipStream_t s) {
     FftState &f = ctx->fft;
-    if (f.cache_enabled && f.V_valid && f.V_owner == V && f.V_dtype == dtype && same_geo(f.V_geo, g)) return TNMF_OK;
-    f.V_valid = false;
-    CHECK(forward_planes(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SV), s));
-    f.V_valid = f.cache_enabled;
-    f.V_owner = V;
-    f.V_geo = g;
-    f.V_dtype = dtype;
+    const bool hit = f.cache_enabled && f.V_valid && f.V_owner == V && f.V_dtype == dtype && same_geo(f.V_geo, g);
+    if (!hit) {
+        f.V_valid = f.SV_valid = false;
+        CHECK(forward_rows(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, at(ctx, l.VT), s));
+        f.V_valid = f.cache_enabled;
+        f.V_owner = V;
+        f.V_geo = g;
+        f.V_dtype = dtype;
+    }
+    if (full && !(hit && f.SV_valid)) {
+        CHECK(columns_of(g, l, dtype, at(ctx, l.VT), g.N * g.C, g.Dy, at(ctx, l.SV), s));
+        f.SV_valid = f.cache_enabled;
+    }
     return TNMF_OK;
 }
 
@@ -291,6 +348,7 @@ void fft_invalidate_H(tnmf_hip_ctx *ctx) { ctx->fft.T_valid = false; }
 void fft_invalidate(tnmf_hip_ctx *ctx) {
     ctx->fft.T_valid = false;
     ctx->fft.V_valid = false;
+    ctx->fft.SV_valid = false;
 }
 
 void fft_release(tnmf_hip_ctx *ctx) {
@@ -299,26 +357,34 @@ void fft_release(tnmf_hip_ctx *ctx) {
     ctx->fft.ws_bytes = 0;
     ctx->fft.T_valid = false;
     ctx->fft.V_valid = false;
+    ctx->fft.SV_valid = false;
 }
 
 int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, bool nonneg,
                     hipStream_t s) {
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l));
-    CHECK(spectra_W(ctx, g, l, dtype, W, true, false, s));
     CHECK(rows_of_H(ctx, g, l, dtype, H, s));
-    FftArgs a = base_args(g, l);
-    a.src0 = at(ctx, l.T);
-    a.src1 = at(ctx, l.SW);
-    a.dst0 = at(ctx, l.SR);
-    CHECK(l.colf(kFftContractR, dtype, &a, s));
-    FftArgs b = base_args(g, l);
-    b.src0 = at(ctx, l.SR);
-    b.dst0 = at(ctx, l.Ts);
-    b.planes = g.N * g.C;
-    b.rows = g.Dy;
-    b.yoff = g.Ay - 1;
-    CHECK(l.colf(kFftColsInv, dtype, &b, s));
+    if (use_mixed(g, dtype)) {
+        // transform along x only; the atom rows are contracted directly (fft_mixed.hip)
+        CHECK(scaled_W(ctx, g, l, dtype, W, 1.0 / l.Lx, s));
+        CHECK(forward_rows(g, l, dtype, at(ctx, l.Wt), g.M * g.C, g.Ay, g.Ax, at(ctx, l.TW), s));
+        CHECK(mixed_reconstruct(g, at(ctx, l.T), at(ctx, l.TW), at(ctx, l.Ts), l.KX, l.KXP, s));
+    } else {
+        CHECK(spectra_W(ctx, g, l, dtype, W, true, false, s));
+        FftArgs a = base_args(g, l);
+        a.src0 = at(ctx, l.T);
+        a.src1 = at(ctx, l.SW);
+        a.dst0 = at(ctx, l.SR);
+        CHECK(l.colf(kFftContractR, dtype, &a, s));
+        FftArgs b = base_args(g, l);
+        b.src0 = at(ctx, l.SR);
+        b.dst0 = at(ctx, l.Ts);
+        b.planes = g.N * g.C;
+        b.rows = g.Dy;
+        b.yoff = g.Ay - 1;
+        CHECK(l.colf(kFftColsInv, dtype, &b, s));
+    }
     FftArgs c = base_args(g, l);
     c.src0 = at(ctx, l.Ts);
     c.dst0 = R;
@@ -338,7 +404,7 @@ namespace {
 int grad_H_spectra(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, const void *R,
                    const void *W, hipStream_t s) {
     CHECK(spectra_W(ctx, g, l, dtype, W, false, true, s));
-    CHECK(spectra_V(ctx, g, l, dtype, V, s));
+    CHECK(spectra_V(ctx, g, l, dtype, V, true, s));
     return forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s);
 }
 
@@ -417,40 +483,60 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l));
     CHECK(rows_of_H(ctx, g, l, dtype, H, s));
-    CHECK(spectra_V(ctx, g, l, dtype, V, s));
-    CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
-    FftArgs a = base_args(g, l);
-    a.src0 = at(ctx, l.T);
-    a.src1 = at(ctx, l.SV);
-    a.src2 = at(ctx, l.SR);
-    a.dst0 = at(ctx, l.Gn);
-    a.dst1 = at(ctx, l.Gp);
-    a.ngroups = l.ngroups;
-    a.nper = l.nper;
-    CHECK(l.colf(kFftGradW, dtype, &a, s));
-    // fixed-order sum of the groups, scaled; both gradients side by side: [2][M*C][Ly][KXP]
-    const long count = (long)g.M * g.C * l.Ly * l.KXP;
-    const size_t sbytes = (size_t)count * l.csz;
-    const double scale = 1.0 / ((double)l.Ly * l.Lx);
-    for (int which = 0; which < 2; ++which) {
-        const char *parts = at(ctx, which ? l.Gp : l.Gn);
-        char *out = at(ctx, l.Gs) + which * sbytes;
-        if (dtype == 0)
-            hipLaunchKernelGGL(k_fft_sum_groups<float>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
-                               (const cplx<float> *)parts, (cplx<float> *)out, count, l.ngroups, scale);
-        else
-            hipLaunchKernelGGL(k_fft_sum_groups<double>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
-                               (const cplx<double> *)parts, (cplx<double> *)out, count, l.ngroups, scale);
-        TNMF_LAUNCH_CHECK();
-    }
+    const bool mixed = use_mixed(g, dtype);
+    CHECK(spectra_V(ctx, g, l, dtype, V, !mixed, s));
     const int planes = 2 * g.M * g.C;
-    FftArgs b = base_args(g, l);
-    b.src0 = at(ctx, l.Gs);
-    b.dst0 = at(ctx, l.TW);   // [2*M*C][Ay][KXP]
-    b.planes = planes;
-    b.rows = g.Ay;
-    b.yoff = 0;
-    CHECK(l.colf(kFftColsInv, dtype, &b, s));
+    if (mixed) {
+        // transform along x only; the Ay lags along y are accumulated directly (fft_mixed.hip)
+        CHECK(forward_rows(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.RT), s));
+        int ng = g.N < 32 ? g.N : 32;
+        const int nper = cdiv(g.N, ng);
+        ng = cdiv(g.N, nper);
+        const int ngpad = (int)align_up((size_t)ng, 4);   // whole blocks of 4 groups; the extra groups write zeros
+        CHECK(mixed_grad_W(g, at(ctx, l.T), at(ctx, l.VT), at(ctx, l.RT), at(ctx, l.Gn), at(ctx, l.Gp), l.KX, l.KXP,
+                           ngpad, nper, s));
+        const long count = (long)g.M * g.C * g.Ay * l.KXP;
+        for (int which = 0; which < 2; ++which) {
+            const char *parts = at(ctx, which ? l.Gp : l.Gn);
+            char *out = at(ctx, l.TW) + which * (size_t)count * l.csz;   // [2*M*C][Ay][KXP]
+            hipLaunchKernelGGL(k_fft_sum_groups<float>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                               (const cplx<float> *)parts, (cplx<float> *)out, count, ngpad, 1.0 / l.Lx);
+            TNMF_LAUNCH_CHECK();
+        }
+    } else {
+        CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
+        FftArgs a = base_args(g, l);
+        a.src0 = at(ctx, l.T);
+        a.src1 = at(ctx, l.SV);
+        a.src2 = at(ctx, l.SR);
+        a.dst0 = at(ctx, l.Gn);
+        a.dst1 = at(ctx, l.Gp);
+        a.ngroups = l.ngroups;
+        a.nper = l.nper;
+        CHECK(l.colf(kFftGradW, dtype, &a, s));
+        // fixed-order sum of the groups, scaled; both gradients side by side: [2][M*C][Ly][KXP]
+        const long count = (long)g.M * g.C * l.Ly * l.KXP;
+        const size_t sbytes = (size_t)count * l.csz;
+        const double scale = 1.0 / ((double)l.Ly * l.Lx);
+        for (int which = 0; which < 2; ++which) {
+            const char *parts = at(ctx, which ? l.Gp : l.Gn);
+            char *out = at(ctx, l.Gs) + which * sbytes;
+            if (dtype == 0)
+                hipLaunchKernelGGL(k_fft_sum_groups<float>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                                   (const cplx<float> *)parts, (cplx<float> *)out, count, l.ngroups, scale);
+            else
+                hipLaunchKernelGGL(k_fft_sum_groups<double>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                                   (const cplx<double> *)parts, (cplx<double> *)out, count, l.ngroups, scale);
+            TNMF_LAUNCH_CHECK();
+        }
+        FftArgs b = base_args(g, l);
+        b.src0 = at(ctx, l.Gs);
+        b.dst0 = at(ctx, l.TW);   // [2*M*C][Ay][KXP]
+        b.planes = planes;
+        b.rows = g.Ay;
+        b.yoff = 0;
+        CHECK(l.colf(kFftColsInv, dtype, &b, s));
+    }
     FftArgs c = base_args(g, l);
     c.src0 = at(ctx, l.TW);
     c.dst0 = at(ctx, l.Wo);

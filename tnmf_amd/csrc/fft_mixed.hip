@@ -1,0 +1,253 @@
+// fft_mixed.hip -- "mixed" contractions of the FFT family: transform along x only, the few taps along y directly.
+//
+// After the row transforms an atom is only Ay rows tall, so the contraction over (atom, atom row) costs Ay complex
+// multiply-adds per row-spectrum entry -- fewer issue slots than the column transform it replaces (two LDS round trips
+// per radix stage) as long as C*Ay stays small -- and needs no LDS and no barrier at all:
+//
+//   reconstruct   OT[n,c,y,kx]  = sum_m sum_a T[n,m,y+a,kx] * WT[m,c,Ay-1-a,kx]          (then C2R along x, crop)
+//   W gradient    GT[m,c,a,kx]  = sum_n sum_y T[n,m,y+a,kx] * conj(VT[n,c,y,kx])        (then C2R along x, crop, flip)
+//
+// T, VT, WT = row spectra (fft_kernels.h).  Same mathematics as NumPy.py:122-132 / 69-91 of the reference with the
+// x axis in the frequency domain.  Lanes run along kx (coalesced 128-byte segments), everything else is registers.
+#include "fft.h"
+
+namespace {
+
+// float only: a complex value is one 64-bit register pair and every complex multiply-add is two packed FMAs whose
+// operand broadcasts, swaps and sign flips ride on the op_sel / neg modifiers (left to itself hipcc materialises the
+// broadcast and swapped operand pairs in extra registers: 300-400 VGPRs for these kernels instead of ~130).
+//   D.lo = A[op_sel[0]] * B[op_sel[1]] + C[op_sel[2]],  D.hi likewise with op_sel_hi
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <typename T>
+struct cplx_of;
+template <>
+struct cplx_of<float> {
+    using type = f2v;
+};
+template <typename T>
+using cplx = typename cplx_of<T>::type;
+
+// acc += a * b
+__device__ __forceinline__ void cfma(f2v &acc, f2v a, f2v b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+}
+// acc += a * conj(b)
+__device__ __forceinline__ void cfmac(f2v &acc, f2v a, f2v b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+#define CHECK(rc_expr)                  \
+    do {                                \
+        const int _rc = (rc_expr);      \
+        if (_rc != TNMF_OK) return _rc; \
+    } while (0)
+
+constexpr int kMixCols = 16;   // kx per block row group: 16 lanes x 8 bytes = one 128-byte segment
+
+// ---- reconstruct ---------------------------------------------------------------------------------------------------
+// block = 16 kx x STRIPS strips of S output rows; a thread keeps S outputs per channel in registers and, per atom, the
+// S+AY-1 row-spectrum entries they depend on.  grid (kx tiles, row blocks, samples)
+template <typename T, int AY, int CG, int S, int STRIPS>
+__global__ __launch_bounds__(kMixCols *STRIPS, 2) void k_mix_reconstruct(const cplx<T> *Tsp, const cplx<T> *WT,
+                                                                      cplx<T> *OT, int M, int C, int Hy, int Dy, int KX,
+                                                                      int KXP) {
+    const int col = threadIdx.x & (kMixCols - 1), strip = threadIdx.x / kMixCols;
+    const int kx = blockIdx.x * kMixCols + col, kxc = min(kx, KX - 1);
+    const int y0 = (blockIdx.y * STRIPS + strip) * S, n = blockIdx.z;
+    cplx<T> acc[CG][S];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+        for (int y = 0; y < S; ++y) acc[c][y] = {0, 0};
+    // element offsets inside a plane do not depend on the atom: uniform plane base + 32-bit per-thread offset.
+    // The rows of the next atom are fetched while the current ones are multiplied (two register sets).
+    unsigned toff[S + AY - 1], woff[AY];
+#pragma unroll
+    for (int r = 0; r < S + AY - 1; ++r) toff[r] = (unsigned)(min(y0 + r, Hy - 1) * KXP + kxc);
+#pragma unroll
+    for (int a = 0; a < AY; ++a) woff[a] = (unsigned)((AY - 1 - a) * KXP + kxc);
+    const long tplane = (long)Hy * KXP, wplane = (long)AY * KXP;
+    cplx<T> t[S + AY - 1], tn[S + AY - 1];
+    {
+        const cplx<T> *tp = Tsp + (long)n * M * tplane;
+#pragma unroll
+        for (int r = 0; r < S + AY - 1; ++r) t[r] = tp[toff[r]];
+    }
+#pragma unroll 1
+    for (int m = 0; m < M; ++m) {
+        cplx<T> w[CG][AY];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const cplx<T> *wp = WT + ((long)m * C + min(c, C - 1)) * wplane;
+#pragma unroll
+            for (int a = 0; a < AY; ++a) w[c][a] = wp[woff[a]];
+        }
+        {
+            const cplx<T> *tp = Tsp + ((long)n * M + min(m + 1, M - 1)) * tplane;
+#pragma unroll
+            for (int r = 0; r < S + AY - 1; ++r) tn[r] = tp[toff[r]];
+        }
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+#pragma unroll
+            for (int a = 0; a < AY; ++a)
+#pragma unroll
+                for (int y = 0; y < S; ++y) cfma(acc[c][y], t[y + a], w[c][a]);
+#pragma unroll
+        for (int r = 0; r < S + AY - 1; ++r) t[r] = tn[r];
+    }
+    if (kx >= KX) return;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        if (c >= C) break;
+#pragma unroll
+        for (int y = 0; y < S; ++y)
+            if (y0 + y < Dy) OT[((long)n * C + c) * ((long)Dy * KXP) + (long)(y0 + y) * KXP + kx] = acc[c][y];
+    }
+}
+
+template <typename T, int AY>
+int launch_mix_reconstruct(const void *Tsp, const void *WT, void *OT, const Geo &g, int KX, int KXP, hipStream_t s) {
+    const unsigned tiles = (unsigned)cdiv(KX, kMixCols);
+    constexpr int S = 16, STRIPS = 8;
+    hipLaunchKernelGGL((k_mix_reconstruct<T, AY, 1, S, STRIPS>), dim3(tiles, (unsigned)cdiv(g.Dy, S * STRIPS), (unsigned)g.N),
+                       dim3(kMixCols * STRIPS), 0, s, (const cplx<T> *)Tsp, (const cplx<T> *)WT, (cplx<T> *)OT, g.M, g.C,
+                       g.Hy, g.Dy, KX, KXP);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+// ---- W gradient ----------------------------------------------------------------------------------------------------
+// block = 16 kx x GROUPS sample groups for one atom; a thread walks the rows of its samples with a rolling window of AY
+// row-spectrum entries and accumulates the AY lags for neg (against VT) and pos (against RT).
+// grid (kx tiles, atoms, sample-group blocks); partial sums [group][M*C][AY][KXP], summed in order afterwards
+template <typename T, int AY, int CG, int GROUPS>
+__global__ __launch_bounds__(kMixCols *GROUPS, 2) void k_mix_grad_W(const cplx<T> *Tsp, const cplx<T> *VT,
+                                                                 const cplx<T> *RT, cplx<T> *Gn, cplx<T> *Gp, int N,
+                                                                 int M, int C, int Hy, int Dy, int KX, int KXP,
+                                                                 int nper) {
+    const int col = threadIdx.x & (kMixCols - 1), sub = threadIdx.x / kMixCols;
+    const int kx = blockIdx.x * kMixCols + col, kxc = min(kx, KX - 1);
+    const int m = blockIdx.y, grp = blockIdx.z * GROUPS + sub;
+    cplx<T> an[CG][AY], ap[CG][AY];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+        for (int a = 0; a < AY; ++a) {
+            an[c][a] = {0, 0};
+            ap[c][a] = {0, 0};
+        }
+    const int nbeg = grp * nper, nend = min(N, nbeg + nper);
+    const long tplane = (long)Hy * KXP, vplane = (long)Dy * KXP;
+    static_assert(CG == 1, "one channel per thread");
+#pragma unroll 1
+    for (int n = nbeg; n < nend; ++n) {
+        const cplx<T> *tp = Tsp + ((long)n * M + m) * tplane;   // uniform bases, 32-bit per-thread offsets
+        const cplx<T> *vp = VT + (long)n * C * vplane, *rp = RT + (long)n * C * vplane;
+        // Rows are taken in blocks of AY: the block [yb, yb+AY) needs T[yb .. yb+2AY-2] and V/R[yb .. yb+AY-1].  The
+        // next block's AY new T rows and its V/R rows are fetched while the current block is accumulated.
+        cplx<T> t[2 * AY - 1], v[AY], r[AY], tn[AY], vn[AY], rn[AY];
+#pragma unroll
+        for (int i = 0; i < 2 * AY - 1; ++i) t[i] = tp[(unsigned)(min(i, Hy - 1) * KXP + kxc)];
+#pragma unroll
+        for (int j = 0; j < AY; ++j) {
+            const unsigned o = (unsigned)(min(j, Dy - 1) * KXP + kxc);
+            v[j] = vp[o];
+            r[j] = rp[o];
+        }
+#pragma unroll 1
+        for (int yb = 0; yb < Dy; yb += AY) {
+#pragma unroll
+            for (int i = 0; i < AY; ++i) tn[i] = tp[(unsigned)(min(yb + 2 * AY - 1 + i, Hy - 1) * KXP + kxc)];
+#pragma unroll
+            for (int j = 0; j < AY; ++j) {
+                const unsigned o = (unsigned)(min(yb + AY + j, Dy - 1) * KXP + kxc);
+                vn[j] = vp[o];
+                rn[j] = rp[o];
+            }
+#pragma unroll
+            for (int j = 0; j < AY; ++j) {
+                if (yb + j >= Dy) {   // rows past the data contribute nothing
+                    v[j] = {0, 0};
+                    r[j] = {0, 0};
+                }
+#pragma unroll
+                for (int a = 0; a < AY; ++a) {
+                    cfmac(an[0][a], t[j + a], v[j]);
+                    cfmac(ap[0][a], t[j + a], r[j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < AY - 1; ++i) t[i] = t[i + AY];
+#pragma unroll
+            for (int i = 0; i < AY; ++i) t[AY - 1 + i] = tn[i];
+#pragma unroll
+            for (int j = 0; j < AY; ++j) {
+                v[j] = vn[j];
+                r[j] = rn[j];
+            }
+        }
+    }
+    if (kx >= KX) return;
+    const long gplane = (long)AY * KXP, gsize = (long)M * C * gplane;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        if (c >= C) break;
+#pragma unroll
+        for (int a = 0; a < AY; ++a) {
+            const long o = (long)grp * gsize + ((long)m * C + c) * gplane + (long)a * KXP + kx;
+            Gn[o] = an[c][a];
+            Gp[o] = ap[c][a];
+        }
+    }
+}
+
+template <typename T, int AY>
+int launch_mix_grad_W(const void *Tsp, const void *VT, const void *RT, void *Gn, void *Gp, const Geo &g, int KX,
+                      int KXP, int ngroups, int nper, hipStream_t s) {
+    constexpr int GROUPS = 4;
+    const dim3 grid((unsigned)cdiv(KX, kMixCols), (unsigned)g.M, (unsigned)cdiv(ngroups, GROUPS));
+    hipLaunchKernelGGL((k_mix_grad_W<T, AY, 1, GROUPS>), grid, dim3(kMixCols * GROUPS), 0, s, (const cplx<T> *)Tsp,
+                       (const cplx<T> *)VT, (const cplx<T> *)RT, (cplx<T> *)Gn, (cplx<T> *)Gp, g.N, g.M, g.C, g.Hy, g.Dy,
+                       KX, KXP, nper);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+#define MIX_SWITCH(FN, ...)                                   \
+    switch (g.Ay) {                                           \
+        case 1: return FN<float, 1>(__VA_ARGS__);             \
+        case 2: return FN<float, 2>(__VA_ARGS__);             \
+        case 3: return FN<float, 3>(__VA_ARGS__);             \
+        case 4: return FN<float, 4>(__VA_ARGS__);             \
+        case 5: return FN<float, 5>(__VA_ARGS__);             \
+        case 6: return FN<float, 6>(__VA_ARGS__);             \
+        case 7: return FN<float, 7>(__VA_ARGS__);             \
+        case 8: return FN<float, 8>(__VA_ARGS__);             \
+        case 9: return FN<float, 9>(__VA_ARGS__);             \
+        case 10: return FN<float, 10>(__VA_ARGS__);           \
+        case 11: return FN<float, 11>(__VA_ARGS__);           \
+        case 12: return FN<float, 12>(__VA_ARGS__);           \
+        case 13: return FN<float, 13>(__VA_ARGS__);           \
+        case 14: return FN<float, 14>(__VA_ARGS__);           \
+        case 15: return FN<float, 15>(__VA_ARGS__);           \
+        case 16: return FN<float, 16>(__VA_ARGS__);           \
+        default: return TNMF_E_UNSUPPORTED;                   \
+    }
+
+}  // namespace
+
+// float32, one channel, atoms up to 16 rows (several channels: the accumulators no longer fit the registers, and the
+// column-transform kernels of fft_kernels.h, whose cost does not grow with C*Ay, take over)
+bool mixed_has(const Geo &g, int dtype) { return dtype == 0 && g.Ay <= 16 && g.C == 1; }
+
+int mixed_reconstruct(const Geo &g, const void *Tsp, const void *WT, void *OT, int KX, int KXP, hipStream_t s) {
+    MIX_SWITCH(launch_mix_reconstruct, Tsp, WT, OT, g, KX, KXP, s);
+}
+
+int mixed_grad_W(const Geo &g, const void *Tsp, const void *VT, const void *RT, void *Gn, void *Gp, int KX, int KXP,
+                 int ngroups, int nper, hipStream_t s) {
+    MIX_SWITCH(launch_mix_grad_W, Tsp, VT, RT, Gn, Gp, g, KX, KXP, ngroups, nper, s);
+}
