@@ -236,6 +236,8 @@ int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom) {
     void *stream = nullptr;
     ENTER(ctx, geom);
     (void)s;
+    if (g.N > 0 && ctx->path == TNMF_PATH_FFT) CHECK(fft_reserve(ctx, g, dtype, true));
+    if (g.N > 0 && use_fft_hybrid(ctx, g, dtype)) CHECK(fft_reserve(ctx, g, dtype, false));
     return ensure_scratch(ctx, plan_scratch(ctx, g, dtype).total);
 }
 

@@ -62,6 +62,8 @@ bool fft_has(const Geo &g, int dtype);
 void fft_invalidate(tnmf_hip_ctx *ctx);     // H and V may have changed
 void fft_invalidate_H(tnmf_hip_ctx *ctx);   // H has changed
 void fft_release(tnmf_hip_ctx *ctx);
+// pre-size the family's workspace for `g` (with_window: including the buffers of the fused FFT H update)
+int fft_reserve(tnmf_hip_ctx *ctx, const Geo &g, int dtype, bool with_window);
 
 // nonneg: clamp R at zero from below (W, H >= 0 make R >= 0; this removes transform rounding noise below zero so
 // that the direct H-gradient kernel keeps its invariant pos >= 0 -- used by the hybrid dispatch)

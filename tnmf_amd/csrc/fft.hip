@@ -351,6 +351,12 @@ void fft_invalidate(tnmf_hip_ctx *ctx) {
     ctx->fft.SV_valid = false;
 }
 
+int fft_reserve(tnmf_hip_ctx *ctx, const Geo &g, int dtype, bool with_window) {
+    Lay l;
+    if (!fft_has(g, dtype) || !make_layout(g, dtype, &l)) return TNMF_E_UNSUPPORTED;
+    return ensure_ws(ctx, with_window ? l.total : l.total_no_window);
+}
+
 void fft_release(tnmf_hip_ctx *ctx) {
     if (ctx->fft.ws) (void)hipFree(ctx->fft.ws);
     ctx->fft.ws = nullptr;
