@@ -495,7 +495,9 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
     if (mixed) {
         // transform along x only; the Ay lags along y are accumulated directly (fft_mixed.hip)
         CHECK(forward_rows(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.RT), s));
-        int ng = g.N < 32 ? g.N : 32;
+        int ng_want = 32;
+        if (const char *e = getenv("TNMF_MIX_GROUPS")) ng_want = atoi(e);
+        int ng = g.N < ng_want ? g.N : ng_want;
         const int nper = cdiv(g.N, ng);
         ng = cdiv(g.N, nper);
         const int ngpad = (int)align_up((size_t)ng, 4);   // whole blocks of 4 groups; the extra groups write zeros
