@@ -52,7 +52,8 @@ TNMF_FFT_DECL(576);
 #undef TNMF_FFT_DECL
 
 // mixed contractions (fft_mixed.hip): transform along x only, the atom rows directly
-bool mixed_has(const Geo &g, int dtype);
+bool mixed_has_reconstruct(const Geo &g, int dtype);
+bool mixed_has_grad_W(const Geo &g, int dtype);
 int mixed_reconstruct(const Geo &g, const void *Tsp, const void *WT, void *OT, int KX, int KXP, hipStream_t s);
 int mixed_grad_W(const Geo &g, const void *Tsp, const void *VT, const void *RT, void *Gn, void *Gp, int KX, int KXP,
                  int ngroups, int nper, hipStream_t s);

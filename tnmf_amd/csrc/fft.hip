@@ -210,9 +210,9 @@ int forward_planes(const Geo &g, const Lay &l, int dtype, const void *src, int p
     return l.colf(kFftColsFwd, dtype, &b, s);
 }
 
-bool use_mixed(const Geo &g, int dtype) {
+bool use_mixed(const Geo &g, int dtype, bool grad_W) {
     static const bool off = getenv("TNMF_FFT_NO_MIXED") != nullptr;   // diagnostic: force the column-transform kernels
-    return !off && mixed_has(g, dtype);
+    return !off && (grad_W ? mixed_has_grad_W(g, dtype) : mixed_has_reconstruct(g, dtype));
 }
 
 // Wt <- scale * W (and its flipped copy behind it)
@@ -371,7 +371,7 @@ int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, c
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l));
     CHECK(rows_of_H(ctx, g, l, dtype, H, s));
-    if (use_mixed(g, dtype)) {
+    if (use_mixed(g, dtype, false)) {
         // transform along x only; the atom rows are contracted directly (fft_mixed.hip)
         CHECK(scaled_W(ctx, g, l, dtype, W, 1.0 / l.Lx, s));
         CHECK(forward_rows(g, l, dtype, at(ctx, l.Wt), g.M * g.C, g.Ay, g.Ax, at(ctx, l.TW), s));
@@ -489,7 +489,7 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l));
     CHECK(rows_of_H(ctx, g, l, dtype, H, s));
-    const bool mixed = use_mixed(g, dtype);
+    const bool mixed = use_mixed(g, dtype, true);
     CHECK(spectra_V(ctx, g, l, dtype, V, !mixed, s));
     const int planes = 2 * g.M * g.C;
     if (mixed) {

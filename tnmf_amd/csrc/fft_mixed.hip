@@ -111,10 +111,19 @@ __global__ __launch_bounds__(kMixCols *STRIPS, 2) void k_mix_reconstruct(const c
 template <typename T, int AY>
 int launch_mix_reconstruct(const void *Tsp, const void *WT, void *OT, const Geo &g, int KX, int KXP, hipStream_t s) {
     const unsigned tiles = (unsigned)cdiv(KX, kMixCols);
-    constexpr int S = 16, STRIPS = 8;
-    hipLaunchKernelGGL((k_mix_reconstruct<T, AY, 1, S, STRIPS>), dim3(tiles, (unsigned)cdiv(g.Dy, S * STRIPS), (unsigned)g.N),
-                       dim3(kMixCols * STRIPS), 0, s, (const cplx<T> *)Tsp, (const cplx<T> *)WT, (cplx<T> *)OT, g.M, g.C,
-                       g.Hy, g.Dy, KX, KXP);
+    if (g.C == 1) {
+        constexpr int S = 16, STRIPS = 8;
+        hipLaunchKernelGGL((k_mix_reconstruct<T, AY, 1, S, STRIPS>),
+                           dim3(tiles, (unsigned)cdiv(g.Dy, S * STRIPS), (unsigned)g.N), dim3(kMixCols * STRIPS), 0, s,
+                           (const cplx<T> *)Tsp, (const cplx<T> *)WT, (cplx<T> *)OT, g.M, g.C, g.Hy, g.Dy, KX, KXP);
+    } else {
+        // up to three channels: shorter strips keep the three accumulator sets and the atom rows of three channels in
+        // registers
+        constexpr int S = 8, STRIPS = 8;
+        hipLaunchKernelGGL((k_mix_reconstruct<T, AY, 3, S, STRIPS>),
+                           dim3(tiles, (unsigned)cdiv(g.Dy, S * STRIPS), (unsigned)g.N), dim3(kMixCols * STRIPS), 0, s,
+                           (const cplx<T> *)Tsp, (const cplx<T> *)WT, (cplx<T> *)OT, g.M, g.C, g.Hy, g.Dy, KX, KXP);
+    }
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
 }
@@ -239,9 +248,12 @@ int launch_mix_grad_W(const void *Tsp, const void *VT, const void *RT, void *Gn,
 
 }  // namespace
 
-// float32, one channel, atoms up to 16 rows (several channels: the accumulators no longer fit the registers, and the
-// column-transform kernels of fft_kernels.h, whose cost does not grow with C*Ay, take over)
-bool mixed_has(const Geo &g, int dtype) { return dtype == 0 && g.Ay <= 16 && g.C == 1; }
+// float32, one channel, atoms up to 16 rows.  With several channels the column-transform kernels of fft_kernels.h,
+// whose cost does not grow with C*Ay, are faster (measured with the three-channel variant of k_mix_reconstruct, which
+// is kept instantiated: config 4 reconstruct 2.5 -> 3.3 ms, config 5 11.0 -> 15.5 ms), and the W gradient's two
+// accumulator sets per channel no longer fit the registers.
+bool mixed_has_reconstruct(const Geo &g, int dtype) { return dtype == 0 && g.Ay <= 16 && g.C == 1; }
+bool mixed_has_grad_W(const Geo &g, int dtype) { return dtype == 0 && g.Ay <= 16 && g.C == 1; }
 
 int mixed_reconstruct(const Geo &g, const void *Tsp, const void *WT, void *OT, int KX, int KXP, hipStream_t s) {
     MIX_SWITCH(launch_mix_reconstruct, Tsp, WT, OT, g, KX, KXP, s);
