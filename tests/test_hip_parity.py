@@ -356,6 +356,53 @@ def test_fft_family_reproduces_reference_known_answers_f64(scenario):
     assert np.isclose(nmf._energy_function(), E)
 
 
+HYBRID_SHAPES = [
+    # N, C, D, M, A -- ragged against every tile size of the row, mixed and column kernels
+    (3, 1, (130, 301), 5, (7, 10)),       # transform lengths 144 x 384, one channel: mixed contractions
+    (2, 2, (77, 45), 9, (16, 3)),         # 96 x 48, two channels: column-transform contractions
+    (5, 1, (33, 500), 3, (1, 16)),        # atoms one row tall, long rows (576)
+    (1, 3, (260, 40), 40, (13, 9)),       # 288 x 48, three channels, more atoms than one tile
+    (7, 1, (20, 20), 33, (5, 5)),         # tiny planes, many of them
+]
+
+
+@pytest.mark.parametrize('shape', HYBRID_SHAPES, ids=[f'{s[0]}x{s[1]}x{"x".join(map(str, s[2]))}_m{s[3]}_a{"x".join(map(str, s[4]))}' for s in HYBRID_SHAPES])
+def test_hybrid_dispatch_on_ragged_shapes(shape):
+    """path='hybrid' (forced, whatever the size) against the float64 oracle on shapes that are ragged against every
+    tile size, with the fused half steps chained so that the cached spectra are exercised."""
+    N, C, D, M, A = shape
+    rng = np.random.default_rng(N * 100 + M)
+    V = rng.random((N, C) + D)
+    Wn = rng.random((M, C) + A)
+    Wn /= Wn.sum(axis=(-2, -1), keepdims=True)
+    Hn = rng.random((N, M) + tuple(d + a - 1 for d, a in zip(D, A)))
+    be = make_backend(V.astype(np.float32), A, M, 'hybrid')
+    W, H = dev(Wn, np.float32), dev(Hn, np.float32)
+    tol = 2e-5
+    assert relmax(be.to_ndarray(be.reconstruct(W, H)), orc.reconstruct(Wn, Hn, 'c')) < tol
+    assert be.last_path == 'fft'
+    on, op = orc.gradient_H(V, Wn, Hn, slice(None), 'c')
+    neg, pos = be.reconstruction_gradient_H(V, W, H)
+    assert be.last_path in ('mfma', 'generic')
+    assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+    on, op = orc.gradient_W(V, Wn, Hn, slice(None), 'c')
+    neg, pos = be.reconstruction_gradient_W(V, W, H)
+    assert be.last_path == 'fft'
+    assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+    # two chained iterations of fused half steps against the oracle's loop
+    Hf, Wf = dev(Hn, np.float32), dev(Wn, np.float32)
+    Ho, Wo = Hn.copy(), Wn.copy()
+    for _ in range(2):
+        be.fused_update_H(V, Wf, Hf, slice(None), sparsity=0., eps=1e-9)
+        be.fused_update_W(V, Wf, Hf, slice(None), eps=1e-9)
+        on, op = orc.gradient_H(V, Wo, Ho, slice(None), 'c')
+        Ho = Ho * on / (op + 1e-9)
+        on, op = orc.gradient_W(V, Wo, Ho, slice(None), 'c')
+        Wo = Wo * on / (op + 1e-9)
+        Wo /= Wo.sum(axis=(-2, -1), keepdims=True)
+    assert relmax(be.to_ndarray(Hf), Ho) < 4 * tol and relmax(be.to_ndarray(Wf), Wo) < 4 * tol
+
+
 def test_kernel_families_agree_over_a_long_run_with_empty_regions():
     """120 float32 iterations on a sparse planted model with an exactly blank band (V == 0: both gradients vanish there,
     the hard case for a float32 frequency-domain update): the hybrid default and the pure FFT family must stay finite
