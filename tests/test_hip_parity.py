@@ -274,6 +274,7 @@ FFT_SHAPES = [
     (2, 1, (5, 6), 2, (5, 6), 'df'),           # 32, 32 (atom as large as the sample)
     (1, 1, (64, 64), 32, (12, 12), 'df'),      # 96, 96
     (5, 5, (24, 40), 3, (3, 7), 'df'),         # 32, 48; more channels than one register group
+    (2, 1, (40, 50), 4, (20, 6), 'df'),        # 64, 64; atoms taller than the mixed contractions take (16 rows)
     (2, 1, (128, 128), 16, (9, 9), 'df'),      # 144, 144
     (2, 3, (100, 170), 8, (12, 12), 'f'),      # 144, 192
     (1, 3, (256, 200), 8, (12, 12), 'f'),      # 288, 288
@@ -363,6 +364,7 @@ HYBRID_SHAPES = [
     (5, 1, (33, 500), 3, (1, 16)),        # atoms one row tall, long rows (576)
     (1, 3, (260, 40), 40, (13, 9)),       # 288 x 48, three channels, more atoms than one tile
     (7, 1, (20, 20), 33, (5, 5)),         # tiny planes, many of them
+    (2, 1, (40, 50), 4, (20, 6)),         # atoms taller than 16 rows: column-transform contractions with one channel
 ]
 
 
