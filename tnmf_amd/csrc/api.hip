@@ -122,7 +122,11 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
 int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
     // the FFT family serves non-negative factorisations: outputs that are non-negative by construction are clamped
-    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype)) return fft_reconstruct(ctx, g, dtype, W, H, R, true, s);
+    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype)) {
+        const int rc = fft_reconstruct(ctx, g, dtype, W, H, R, true, s);
+        // AUTO only chose the family for speed: when its workspace does not fit, the direct kernels still do the job
+        if (!(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
+    }
     if (use_mfma(ctx, g, dtype, kReconstruct)) {
         ctx->last_path = "mfma";
         return mfma_reconstruct(ctx, g, (const float *)W, (const float *)H, (float *)R, s);
@@ -158,8 +162,10 @@ int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, con
         TNMF_HIP_TRY(hipMemsetAsync(pos, 0, (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype), s));
         return TNMF_OK;
     }
-    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype))
-        return fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, true, s);
+    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype)) {
+        const int rc = fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, true, s);
+        if (!(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
+    }
     if (use_mfma(ctx, g, dtype, kCorrH)) {
         ctx->last_path = "mfma";
         P = mfma_corr_H_chunks(ctx, g);
@@ -237,7 +243,10 @@ int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom) {
     ENTER(ctx, geom);
     (void)s;
     if (g.N > 0 && ctx->path == TNMF_PATH_FFT) CHECK(fft_reserve(ctx, g, dtype, true));
-    if (g.N > 0 && use_fft_hybrid(ctx, g, dtype)) CHECK(fft_reserve(ctx, g, dtype, false));
+    if (g.N > 0 && use_fft_hybrid(ctx, g, dtype)) {
+        const int rc = fft_reserve(ctx, g, dtype, false);
+        if (rc != TNMF_OK && !(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
+    }
     return ensure_scratch(ctx, plan_scratch(ctx, g, dtype).total);
 }
 
