@@ -447,7 +447,7 @@ def test_auto_dispatch_at_baseline_sizes(C, D, M, A):
     family, the H gradient and the fused H update on the matrix-core kernels -- and every result, the updated H
     included, agrees with the generic kernels at the tolerance of the direct path."""
     rng = np.random.default_rng(6)
-    N = 16 if M == 16 else 4          # at least 2^22 activation entries: the threshold of the hybrid dispatch
+    N = 16 if M == 16 else 4          # well above 2^19 activation entries, the threshold of the hybrid dispatch
     V = rng.random((N, C) + D).astype(np.float32)
     Wn = rng.random((M, C) + A).astype(np.float32)
     Hn = rng.random((N, M) + tuple(d + a - 1 for d, a in zip(D, A))).astype(np.float32)

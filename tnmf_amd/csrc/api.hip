@@ -84,13 +84,15 @@ inline char *ws_at(tnmf_hip_ctx *ctx, size_t off) { return static_cast<char *>(c
 enum Prim { kReconstruct, kCorrW, kCorrH };
 
 // FFT family for reconstruct and the W gradient (the hybrid dispatch): forced by TNMF_PATH_HYBRID wherever the family
-// covers the shape; chosen by TNMF_PATH_AUTO for float32 problems large enough to fill the chip with transform tiles.
+// covers the shape; chosen by TNMF_PATH_AUTO for float32 problems that are not tiny (the family costs ~20 launches per iteration).
 // Measured: W, H and the energy stay as close to the float64 oracle as with the direct kernels alone,
 // because the H gradient -- the only place where float32 transform error matters -- stays on the direct kernels.
 bool use_fft_hybrid(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
     if (ctx->path == TNMF_PATH_HYBRID) return fft_has(g, dtype);
     if (ctx->path != TNMF_PATH_AUTO || dtype != 0 || !fft_has(g, dtype)) return false;
-    return (size_t)g.N * g.M * g.Hy * g.Hx >= ((size_t)1 << 22);
+    // measured crossover against the direct kernels at 128x128 samples, 16 atoms: one sample (2^18 entries) is a tie,
+    // two are 20 % ahead, 64 samples (config 2) 1.9x
+    return (size_t)g.N * g.M * g.Hy * g.Hx >= ((size_t)1 << 19);
 }
 
 bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
