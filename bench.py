@@ -2,7 +2,8 @@
 """
 bench.py -- MU-iterations/sec of the shift-invariant multiplicative-update loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--path auto|generic|mfma] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--path auto|generic|mfma|fft|hybrid]
+                    [--no-cpu-baseline] [--no-fft-variant]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -16,8 +17,14 @@ the only exchange is one all-reduce (RCCL) of the 2 x 32 x 1 x 12 x 12 W numerat
 MU-iterations/sec of the 256-sample problem and at --gpus N the iterations/sec of N such problems run as one job.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (by time): algorithmic FLOP per launch / average launch duration from HIP events
-                recorded on the launch stream inside the timed region; peak = 157.3 TFLOP/s (f32 MFMA = f32 vector).
+  roofline      dominant kernel group (by time) of the main leg; average launch duration from HIP events recorded on the
+                launch stream inside the timed region.  A group on the matrix-core kernels is priced as algorithmic FLOP
+                of the direct formulation per launch against 157.3 TFLOP/s (f32 MFMA = f32 vector); a group on the FFT
+                family as the bytes that formulation must stream per launch against 8 TB/s HBM.
+                `traffic` = HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json).
+                roofline_by_kernel holds the same entry for every group.
+  direct_variant, fft_variant   (--gpus 1 only) the same iterations from the same start with every group forced onto
+                one kernel family (path='mfma' / path='fft'): speed relative to the main leg and max |dW| / max |W|.
   cpu_baseline  the CPU oracle ("port" of the reference NumPy backend's algorithm: windows + tensordot contraction)
                 timed on a bounded sample of the same workload on this box's host cores (rank 0, --gpus 1 only).
 """
