@@ -22,6 +22,7 @@ struct FftState {
     bool cache_enabled;      // the caller vouches that H and V only change through this library or are announced
                              // with tnmf_hip_ctx_invalidate (tnmf_hip_ctx_set_cache)
     bool T_valid;            // the workspace holds the row spectra of T_owner for T_geo / T_dtype
+    bool SH_valid;           // ... and their column transforms (full spectra of H) as well
     const void *T_owner;
     Geo T_geo;
     int T_dtype;

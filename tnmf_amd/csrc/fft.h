@@ -58,6 +58,12 @@ int mixed_reconstruct(const Geo &g, const void *Tsp, const void *WT, void *OT, i
 int mixed_grad_W(const Geo &g, const void *Tsp, const void *VT, const void *RT, void *Gn, void *Gp, int KX, int KXP,
                  int ngroups, int nper, hipStream_t s);
 
+// streaming contractions on resident full spectra of H (fft_spectral.hip): no transform inside
+int spectral_contract_R(const Geo &g, int dtype, const void *SH, const void *SW, void *SR, int Ly, int KX, int KXP,
+                        hipStream_t s);
+int spectral_grad_W(const Geo &g, int dtype, const void *SH, const void *SV, const void *SR, void *Gn, void *Gp, int Ly,
+                    int KX, int KXP, int ngroups, int nper, hipStream_t s);
+
 // shape support (2-D problems, transform length available for the activation shape, dtype instantiated)
 bool fft_has(const Geo &g, int dtype);
 void fft_invalidate(tnmf_hip_ctx *ctx);     // H and V may have changed

@@ -39,12 +39,15 @@ fft_run_fn lookup(int L) {
     }
 }
 
+bool use_mixed(const Geo &g, int dtype, bool grad_W);
+
 // workspace layout, in bytes
 struct Lay {
     int Ly, Lx, KX, KXP, ngroups, nper, chunk, mgroups, mper;
     fft_run_fn rowf, colf;
     size_t csz;  // bytes of one complex element
-    size_t T, Tn, Tp, SV, SR, Ts, VT, RT, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total, total_no_window;
+    size_t T, SH, Tn, Tp, SV, SR, Ts, VT, RT, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total, total_no_window;
+    bool resident;   // full spectra of H are kept (SH): the contractions stream them instead of transforming tiles
 };
 
 bool make_layout(const Geo &g, int dtype, Lay *l) {
@@ -91,6 +94,10 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
         return at;
     };
     l->T = take(nT);
+    // Problems the mixed kernels do not cover (several channels, tall atoms) keep the full spectra of H resident: one
+    // column-transform pass per H, then every contraction is a plain streaming kernel (fft_spectral.hip)
+    l->resident = !(use_mixed(g, dtype, false) && use_mixed(g, dtype, true));
+    l->SH = take(l->resident ? (size_t)g.N * g.M * l->Ly * kxp * c : 0);
     l->SV = take(nS);
     l->SR = take(nS);
     l->Ts = take((size_t)g.N * g.C * g.Dy * kxp * c);
@@ -123,7 +130,7 @@ int ensure_ws(tnmf_hip_ctx *ctx, size_t bytes) {
         f.ws = nullptr;
         f.ws_bytes = 0;
     }
-    f.T_valid = false;
+    f.T_valid = f.SH_valid = false;
     f.V_valid = f.SV_valid = false;
     const size_t want = align_up(bytes, 1 << 20);
     if (hipMalloc(&f.ws, want) != hipSuccess) {
@@ -259,6 +266,7 @@ bool T_is_current(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *
 void T_mark(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
     FftState &f = ctx->fft;
     f.T_valid = f.cache_enabled;
+    f.SH_valid = false;
     f.T_owner = H;
     f.T_geo = g;
     f.T_dtype = dtype;
@@ -315,6 +323,7 @@ int spectra_V(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const vo
 // row spectra of H into the workspace (skipped when the cache holds them)
 int rows_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *H, hipStream_t s) {
     if (T_is_current(ctx, g, dtype, H)) return TNMF_OK;
+    ctx->fft.SH_valid = false;
     FftArgs a = base_args(g, l);
     a.src0 = H;
     a.dst0 = at(ctx, l.T);
@@ -326,6 +335,15 @@ int rows_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const vo
     a.ps_dst = (long)g.Hy * l.KXP;
     CHECK(l.rowf(kFftRowsFwd, dtype, &a, s));
     T_mark(ctx, g, dtype, H);
+    return TNMF_OK;
+}
+
+// full spectra of H (column transforms of its row spectra) into SH, once per H
+int spectra_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *H, hipStream_t s) {
+    CHECK(rows_of_H(ctx, g, l, dtype, H, s));
+    if (ctx->fft.SH_valid && ctx->fft.T_valid) return TNMF_OK;
+    CHECK(columns_of(g, l, dtype, at(ctx, l.T), g.N * g.M, g.Hy, at(ctx, l.SH), s));
+    ctx->fft.SH_valid = ctx->fft.T_valid;   // only as good as the row spectra it came from
     return TNMF_OK;
 }
 
@@ -343,10 +361,10 @@ bool fft_has(const Geo &g, int dtype) {
     return pick_len(g.Hy, dtype) != 0 && pick_len(g.Hx, dtype) != 0;
 }
 
-void fft_invalidate_H(tnmf_hip_ctx *ctx) { ctx->fft.T_valid = false; }
+void fft_invalidate_H(tnmf_hip_ctx *ctx) { ctx->fft.T_valid = ctx->fft.SH_valid = false; }
 
 void fft_invalidate(tnmf_hip_ctx *ctx) {
-    ctx->fft.T_valid = false;
+    ctx->fft.T_valid = ctx->fft.SH_valid = false;
     ctx->fft.V_valid = false;
     ctx->fft.SV_valid = false;
 }
@@ -361,7 +379,7 @@ void fft_release(tnmf_hip_ctx *ctx) {
     if (ctx->fft.ws) (void)hipFree(ctx->fft.ws);
     ctx->fft.ws = nullptr;
     ctx->fft.ws_bytes = 0;
-    ctx->fft.T_valid = false;
+    ctx->fft.T_valid = ctx->fft.SH_valid = false;
     ctx->fft.V_valid = false;
     ctx->fft.SV_valid = false;
 }
@@ -378,11 +396,16 @@ int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, c
         CHECK(mixed_reconstruct(g, at(ctx, l.T), at(ctx, l.TW), at(ctx, l.Ts), l.KX, l.KXP, s));
     } else {
         CHECK(spectra_W(ctx, g, l, dtype, W, true, false, s));
-        FftArgs a = base_args(g, l);
-        a.src0 = at(ctx, l.T);
-        a.src1 = at(ctx, l.SW);
-        a.dst0 = at(ctx, l.SR);
-        CHECK(l.colf(kFftContractR, dtype, &a, s));
+        if (l.resident && !getenv("TNMF_FFT_NO_RESIDENT")) {
+            CHECK(spectra_of_H(ctx, g, l, dtype, H, s));
+            CHECK(spectral_contract_R(g, dtype, at(ctx, l.SH), at(ctx, l.SW), at(ctx, l.SR), l.Ly, l.KX, l.KXP, s));
+        } else {
+            FftArgs a = base_args(g, l);
+            a.src0 = at(ctx, l.T);
+            a.src1 = at(ctx, l.SW);
+            a.dst0 = at(ctx, l.SR);
+            CHECK(l.colf(kFftContractR, dtype, &a, s));
+        }
         FftArgs b = base_args(g, l);
         b.src0 = at(ctx, l.SR);
         b.dst0 = at(ctx, l.Ts);
@@ -461,7 +484,7 @@ int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, cons
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l, true));
     CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));
-    ctx->fft.T_valid = false;
+    ctx->fft.T_valid = ctx->fft.SH_valid = false;
     const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hx, tplane = (size_t)g.M * g.Hy * l.KXP;
     for (int n0 = 0; n0 < g.N; n0 += l.chunk) {
         const int cnt = g.N - n0 < l.chunk ? g.N - n0 : l.chunk;
@@ -513,15 +536,21 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
         }
     } else {
         CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
-        FftArgs a = base_args(g, l);
-        a.src0 = at(ctx, l.T);
-        a.src1 = at(ctx, l.SV);
-        a.src2 = at(ctx, l.SR);
-        a.dst0 = at(ctx, l.Gn);
-        a.dst1 = at(ctx, l.Gp);
-        a.ngroups = l.ngroups;
-        a.nper = l.nper;
-        CHECK(l.colf(kFftGradW, dtype, &a, s));
+        if (l.resident && !getenv("TNMF_FFT_NO_RESIDENT")) {
+            CHECK(spectra_of_H(ctx, g, l, dtype, H, s));
+            CHECK(spectral_grad_W(g, dtype, at(ctx, l.SH), at(ctx, l.SV), at(ctx, l.SR), at(ctx, l.Gn), at(ctx, l.Gp),
+                                  l.Ly, l.KX, l.KXP, l.ngroups, l.nper, s));
+        } else {
+            FftArgs a = base_args(g, l);
+            a.src0 = at(ctx, l.T);
+            a.src1 = at(ctx, l.SV);
+            a.src2 = at(ctx, l.SR);
+            a.dst0 = at(ctx, l.Gn);
+            a.dst1 = at(ctx, l.Gp);
+            a.ngroups = l.ngroups;
+            a.nper = l.nper;
+            CHECK(l.colf(kFftGradW, dtype, &a, s));
+        }
         // fixed-order sum of the groups, scaled; both gradients side by side: [2][M*C][Ly][KXP]
         const long count = (long)g.M * g.C * l.Ly * l.KXP;
         const size_t sbytes = (size_t)count * l.csz;

@@ -1,0 +1,135 @@
+// fft_spectral.hip -- contractions on RESIDENT full spectra of the activations.
+//
+// Problems the mixed kernels (fft_mixed.hip) do not cover -- several channels, atoms taller than 16 rows -- keep the
+// column transforms of H in the workspace: they are computed once per H (k_fft_cols_fwd) and serve both reconstructs
+// and the W gradient of an iteration, which then are plain streaming kernels with no transform, no LDS and no barrier:
+//
+//   R^[n,c,f]  = sum_m H^[n,m,f] * W^[m,c,f]            (reconstruct, NumPy.py:122-132 in the frequency domain)
+//   G^[m,c,f]  = sum_n H^[n,m,f] * conj(V^[n,c,f])      (W gradient, NumPy.py:69-91; pos with R^)
+//
+// f runs over the Ly * KXP entries of a full-spectrum plane; lanes run along f.
+#include "fft.h"
+#include "fft_engine.h"
+
+namespace {
+
+constexpr int kSpecThreads = 256;
+constexpr int kSpecCG = 4;   // channels accumulated per pass
+
+constexpr int kSpecNS = 4;   // samples per thread in the reconstruct contraction (W^ entries loaded once for all of them)
+constexpr int kSpecMS = 4;   // atoms per thread in the W-gradient contraction (V^, R^ entries loaded once for all of them)
+
+// grid (sample quads, f in blocks of 256, channel groups): every thread owns one f of kSpecNS samples and loops the
+// atoms.  The sample index runs fastest over the blocks so that the blocks in flight share the W^ entries of one f
+// block (L2).
+template <typename T>
+__global__ __launch_bounds__(kSpecThreads) void k_spec_contract_R(const cplx<T> *SH, const cplx<T> *SW, cplx<T> *SR, int N,
+                                                                int M, int C, long plane, int KX, int KXP) {
+    const long f = (long)blockIdx.y * kSpecThreads + threadIdx.x;
+    if (f >= plane || (int)(f % KXP) >= KX) return;   // the pad columns of a spectrum row hold nothing
+    const int n0 = blockIdx.x * kSpecNS, c0 = blockIdx.z * kSpecCG;
+    cplx<T> acc[kSpecNS][kSpecCG];
+#pragma unroll
+    for (int i = 0; i < kSpecNS; ++i)
+#pragma unroll
+        for (int c = 0; c < kSpecCG; ++c) acc[i][c] = {0, 0};
+    for (int m = 0; m < M; ++m) {
+        cplx<T> w[kSpecCG], hv[kSpecNS];
+#pragma unroll
+        for (int c = 0; c < kSpecCG; ++c) w[c] = SW[((long)m * C + (c0 + c < C ? c0 + c : C - 1)) * plane + f];
+#pragma unroll
+        for (int i = 0; i < kSpecNS; ++i) hv[i] = SH[((long)(n0 + i < N ? n0 + i : N - 1) * M + m) * plane + f];
+#pragma unroll
+        for (int i = 0; i < kSpecNS; ++i)
+#pragma unroll
+            for (int c = 0; c < kSpecCG; ++c) cfma(acc[i][c], hv[i], w[c]);
+    }
+#pragma unroll
+    for (int i = 0; i < kSpecNS; ++i)
+#pragma unroll
+        for (int c = 0; c < kSpecCG; ++c)
+            if (n0 + i < N && c0 + c < C) SR[((long)(n0 + i) * C + c0 + c) * plane + f] = acc[i][c];
+}
+
+// grid (atom quads, f in blocks of 256, sample groups * channel groups): every thread owns one f of kSpecMS atoms and
+// sums over the samples of its group; partial sums [group][M*C][plane], added up in group order afterwards.  The atom
+// index runs fastest over the blocks so that the blocks in flight share the V^, R^ entries of one f block (L2).
+template <typename T>
+__global__ __launch_bounds__(kSpecThreads) void k_spec_grad_W(const cplx<T> *SH, const cplx<T> *SV, const cplx<T> *SR,
+                                                            cplx<T> *Gn, cplx<T> *Gp, int N, int M, int C, long plane,
+                                                            int ngroups, int nper, int KX, int KXP) {
+    const long f = (long)blockIdx.y * kSpecThreads + threadIdx.x;
+    if (f >= plane || (int)(f % KXP) >= KX) return;
+    const int m0 = blockIdx.x * kSpecMS, grp = blockIdx.z % ngroups, c0 = (blockIdx.z / ngroups) * kSpecCG;
+    cplx<T> an[kSpecMS][kSpecCG], ap[kSpecMS][kSpecCG];
+#pragma unroll
+    for (int i = 0; i < kSpecMS; ++i)
+#pragma unroll
+        for (int c = 0; c < kSpecCG; ++c) {
+            an[i][c] = {0, 0};
+            ap[i][c] = {0, 0};
+        }
+    const int nbeg = grp * nper, nend = nbeg + nper < N ? nbeg + nper : N;
+    for (int n = nbeg; n < nend; ++n) {
+        cplx<T> v[kSpecCG], r[kSpecCG], hv[kSpecMS];
+#pragma unroll
+        for (int c = 0; c < kSpecCG; ++c) {
+            const long o = ((long)n * C + (c0 + c < C ? c0 + c : C - 1)) * plane + f;
+            v[c] = SV[o];
+            r[c] = SR[o];
+        }
+#pragma unroll
+        for (int i = 0; i < kSpecMS; ++i) hv[i] = SH[((long)n * M + (m0 + i < M ? m0 + i : M - 1)) * plane + f];
+#pragma unroll
+        for (int i = 0; i < kSpecMS; ++i)
+#pragma unroll
+            for (int c = 0; c < kSpecCG; ++c) {
+                cfmac(an[i][c], hv[i], v[c]);
+                cfmac(ap[i][c], hv[i], r[c]);
+            }
+    }
+    const long gsize = (long)M * C * plane;
+#pragma unroll
+    for (int i = 0; i < kSpecMS; ++i)
+#pragma unroll
+        for (int c = 0; c < kSpecCG; ++c)
+            if (m0 + i < M && c0 + c < C) {
+                const long o = (long)grp * gsize + ((long)(m0 + i) * C + c0 + c) * plane + f;
+                Gn[o] = an[i][c];
+                Gp[o] = ap[i][c];
+            }
+}
+
+}  // namespace
+
+int spectral_contract_R(const Geo &g, int dtype, const void *SH, const void *SW, void *SR, int Ly, int KX, int KXP,
+                        hipStream_t s) {
+    const long plane = (long)Ly * KXP;
+    const dim3 grid((unsigned)cdiv(g.N, kSpecNS), (unsigned)((plane + kSpecThreads - 1) / kSpecThreads),
+                    (unsigned)cdiv(g.C, kSpecCG));
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_spec_contract_R<float>, grid, dim3(kSpecThreads), 0, s, (const cplx<float> *)SH,
+                           (const cplx<float> *)SW, (cplx<float> *)SR, g.N, g.M, g.C, plane, KX, KXP);
+    else
+        hipLaunchKernelGGL(k_spec_contract_R<double>, grid, dim3(kSpecThreads), 0, s, (const cplx<double> *)SH,
+                           (const cplx<double> *)SW, (cplx<double> *)SR, g.N, g.M, g.C, plane, KX, KXP);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int spectral_grad_W(const Geo &g, int dtype, const void *SH, const void *SV, const void *SR, void *Gn, void *Gp, int Ly,
+                    int KX, int KXP, int ngroups, int nper, hipStream_t s) {
+    const long plane = (long)Ly * KXP;
+    const dim3 grid((unsigned)cdiv(g.M, kSpecMS), (unsigned)((plane + kSpecThreads - 1) / kSpecThreads),
+                    (unsigned)(ngroups * cdiv(g.C, kSpecCG)));
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_spec_grad_W<float>, grid, dim3(kSpecThreads), 0, s, (const cplx<float> *)SH,
+                           (const cplx<float> *)SV, (const cplx<float> *)SR, (cplx<float> *)Gn, (cplx<float> *)Gp, g.N, g.M,
+                           g.C, plane, ngroups, nper, KX, KXP);
+    else
+        hipLaunchKernelGGL(k_spec_grad_W<double>, grid, dim3(kSpecThreads), 0, s, (const cplx<double> *)SH,
+                           (const cplx<double> *)SV, (const cplx<double> *)SR, (cplx<double> *)Gn, (cplx<double> *)Gp, g.N,
+                           g.M, g.C, plane, ngroups, nper, KX, KXP);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
