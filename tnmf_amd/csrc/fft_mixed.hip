@@ -131,15 +131,16 @@ int launch_mix_reconstruct(const void *Tsp, const void *WT, void *OT, const Geo 
 // ---- W gradient ----------------------------------------------------------------------------------------------------
 // block = 16 kx x GROUPS sample groups for one atom; a thread walks the rows of its samples with a rolling window of AY
 // row-spectrum entries and accumulates the AY lags for neg (against VT) and pos (against RT).
-// grid (kx tiles, atoms, sample-group blocks); partial sums [group][M*C][AY][KXP], summed in order afterwards
+// grid (atoms, kx tiles, sample-group blocks); partial sums [group][M*C][AY][KXP], summed in order afterwards
 template <typename T, int AY, int CG, int GROUPS>
 __global__ __launch_bounds__(kMixCols *GROUPS, 2) void k_mix_grad_W(const cplx<T> *Tsp, const cplx<T> *VT,
                                                                  const cplx<T> *RT, cplx<T> *Gn, cplx<T> *Gp, int N,
                                                                  int M, int C, int Hy, int Dy, int KX, int KXP,
                                                                  int nper) {
     const int col = threadIdx.x & (kMixCols - 1), sub = threadIdx.x / kMixCols;
-    const int kx = blockIdx.x * kMixCols + col, kxc = min(kx, KX - 1);
-    const int m = blockIdx.y, grp = blockIdx.z * GROUPS + sub;
+    // the atom index runs fastest over the blocks: the blocks in flight share the V^/R^ rows of one kx tile (L2)
+    const int kx = blockIdx.y * kMixCols + col, kxc = min(kx, KX - 1);
+    const int m = blockIdx.x, grp = blockIdx.z * GROUPS + sub;
     cplx<T> an[CG][AY], ap[CG][AY];
 #pragma unroll
     for (int c = 0; c < CG; ++c)
@@ -217,7 +218,7 @@ template <typename T, int AY>
 int launch_mix_grad_W(const void *Tsp, const void *VT, const void *RT, void *Gn, void *Gp, const Geo &g, int KX,
                       int KXP, int ngroups, int nper, hipStream_t s) {
     constexpr int GROUPS = 4;
-    const dim3 grid((unsigned)cdiv(KX, kMixCols), (unsigned)g.M, (unsigned)cdiv(ngroups, GROUPS));
+    const dim3 grid((unsigned)g.M, (unsigned)cdiv(KX, kMixCols), (unsigned)cdiv(ngroups, GROUPS));
     hipLaunchKernelGGL((k_mix_grad_W<T, AY, 1, GROUPS>), grid, dim3(kMixCols * GROUPS), 0, s, (const cplx<T> *)Tsp,
                        (const cplx<T> *)VT, (const cplx<T> *)RT, (cplx<T> *)Gn, (cplx<T> *)Gp, g.N, g.M, g.C, g.Hy, g.Dy,
                        KX, KXP, nper);
