@@ -222,6 +222,11 @@ bool use_mixed(const Geo &g, int dtype, bool grad_W) {
     return !off && (grad_W ? mixed_has_grad_W(g, dtype) : mixed_has_reconstruct(g, dtype));
 }
 
+bool use_resident(const Lay &l) {
+    static const bool off = getenv("TNMF_FFT_NO_RESIDENT") != nullptr;   // diagnostic: contract inside the column kernels
+    return l.resident && !off;
+}
+
 // Wt <- scale * W (and its flipped copy behind it)
 int scaled_W(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *W, double scale, hipStream_t s) {
     const int planes = g.M * g.C, n = planes * g.Ay * g.Ax;
@@ -396,7 +401,7 @@ int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, c
         CHECK(mixed_reconstruct(g, at(ctx, l.T), at(ctx, l.TW), at(ctx, l.Ts), l.KX, l.KXP, s));
     } else {
         CHECK(spectra_W(ctx, g, l, dtype, W, true, false, s));
-        if (l.resident && !getenv("TNMF_FFT_NO_RESIDENT")) {
+        if (use_resident(l)) {
             CHECK(spectra_of_H(ctx, g, l, dtype, H, s));
             CHECK(spectral_contract_R(g, dtype, at(ctx, l.SH), at(ctx, l.SW), at(ctx, l.SR), l.Ly, l.KX, l.KXP, s));
         } else {
@@ -536,7 +541,7 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
         }
     } else {
         CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
-        if (l.resident && !getenv("TNMF_FFT_NO_RESIDENT")) {
+        if (use_resident(l)) {
             CHECK(spectra_of_H(ctx, g, l, dtype, H, s));
             CHECK(spectral_grad_W(g, dtype, at(ctx, l.SH), at(ctx, l.SV), at(ctx, l.SR), at(ctx, l.Gn), at(ctx, l.Gp),
                                   l.Ly, l.KX, l.KXP, l.ngroups, l.nper, s));
