@@ -2,8 +2,8 @@
 """
 bench.py -- MU-iterations/sec of the shift-invariant multiplicative-update loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--path auto|generic|mfma|fft|hybrid]
-                    [--no-cpu-baseline] [--no-fft-variant]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--path auto|generic|mfma|split|fft|hybrid]
+                    [--algorithm full|cyclic --batch-size B] [--no-cpu-baseline] [--no-fft-variant] [--no-parity]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -16,15 +16,26 @@ the only exchange is one all-reduce (RCCL) of the 2 x 32 x 1 x 12 x 12 W numerat
 `value` = (shard-iterations completed by all ranks) / (max-over-ranks wall time), i.e. at --gpus 1 exactly the
 MU-iterations/sec of the 256-sample problem and at --gpus N the iterations/sec of N such problems run as one job.
 
+--algorithm cyclic: one step = one Cyclic-MU epoch (reference TransformInvariantNMF.py:457-465) over the rank's samples in
+mini-batches of --batch-size (global batch = the union of the ranks' local batches; one all-reduce per epoch) -- the
+way BASELINE.json words configs 4 and 5.  Same kernels, same work per step as a full-batch iteration.
+
 Extra objects on the JSON line:
   roofline      dominant kernel group (by time) of the main leg; average launch duration from HIP events recorded on the
-                launch stream inside the timed region.  A group on the matrix-core kernels is priced as algorithmic FLOP
-                of the direct formulation per launch against 157.3 TFLOP/s (f32 MFMA = f32 vector); a group on the FFT
-                family as the bytes that formulation must stream per launch against 8 TB/s HBM.
-                `traffic` = HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json).
+                launch stream inside the timed region, priced against WHAT IS EXECUTED: a group on the exact f32 matrix
+                cores as algorithmic FLOP of the direct formulation per launch against 157.3 TFLOP/s (f32 MFMA = f32
+                vector); a group on the split kernel (3 x bf16 operand splits) as the 6 bf16 MFMA products it issues
+                per algorithmic product against the dense bf16 peak (2500 TFLOP/s); a group on the FFT family as the
+                bytes that formulation must stream per launch against 8 TB/s HBM.
+                `traffic` = HBM bytes per launch from the committed PMC passes (profiles/rNN_traffic.json).
                 roofline_by_kernel holds the same entry for every group.
-  direct_variant, fft_variant   (--gpus 1 only) the same iterations from the same start with every group forced onto
-                one kernel family (path='mfma' / path='fft'): speed relative to the main leg and max |dW| / max |W|.
+  parity        the other half of BASELINE.json's metric: the same code path (same --path) run for 5 iterations from
+                the reference's seeded start (np.random.seed(42), H drawn before W) on the first `samples` samples of
+                the workload, against the float64 C oracle on the same samples: max |dW| / max |W|, max |dH| / max |H|,
+                relative energy gap.  Outside the timed region.
+  exact_f32_variant, direct_variant, fft_variant   (--gpus 1 only) the same iterations from the same start with the H
+                update on the exact f32 MFMA (split off), with every group on the direct f32 kernels (path='mfma'), on
+                the FFT family (path='fft'): speed relative to the main leg and max |dW| / max |W| against it.
   cpu_baseline  the CPU oracle ("port" of the reference NumPy backend's algorithm: windows + tensordot contraction)
                 timed on a bounded sample of the same workload on this box's host cores (rank 0, --gpus 1 only).
 """
@@ -49,6 +60,7 @@ CONFIGS = {
     5: dict(N=128, C=3, D=(512, 512), M=64, A=(16, 16)),   # per-GPU shard of the 1024-sample problem
 }
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector = f32 MFMA
+PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -87,15 +99,19 @@ def synth_V_on_device(cfg, n_local, seed, device):
 
 
 def measured_traffic(kernel_name, cfg_id, family):
-    """HBM bytes per launch of a kernel group from the committed PMC passes (profiles/r01_traffic.json, config 3)."""
-    f = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-    if cfg_id != 3 or not os.path.exists(f):
+    """HBM bytes per launch of a kernel group from the committed PMC passes (newest profiles/rNN_traffic.json that has
+    the group on this family; config 3 only)."""
+    import glob
+    if cfg_id != 3:
         return None
-    try:
-        entry = json.load(open(f))['kernels'][kernel_name]
-        return entry['traffic_bytes'] if entry.get('family', 'mfma') == family else None
-    except (KeyError, ValueError):
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+        try:
+            entry = json.load(open(f))['kernels'][kernel_name]
+            if entry.get('family', 'mfma') == family:
+                return entry['traffic_bytes']
+        except (KeyError, ValueError, OSError):
+            continue
+    return None
 
 
 def cpu_baseline(cfg, budget_s=20.0):
@@ -105,19 +121,27 @@ def cpu_baseline(cfg, budget_s=20.0):
     k = len(cfg['A'])
     Dp = tuple(d + a - 1 for d, a in zip(cfg['D'], cfg['A']))
 
-    def run(n):
+    def run(n, chunk):
         V = rng.random((n, cfg['C']) + tuple(cfg['D']), dtype=np.float32)
         W = rng.random((cfg['M'], cfg['C']) + tuple(cfg['A']), dtype=np.float32)
         W /= W.sum(axis=tuple(range(-k, 0)), keepdims=True)
         H = rng.random((n, cfg['M']) + Dp, dtype=np.float32)
         t0 = time.perf_counter()
-        orc.mu_iteration_chunked(V, W, H, chunk=1)
+        orc.mu_iteration_chunked(V, W, H, chunk=chunk)
         return time.perf_counter() - t0
 
-    t1 = run(1)
-    n = int(max(1, min(32, budget_s // max(t1, 1e-3))))   # ~budget_s seconds of host work
-    t = run(n) if n > 1 else t1
-    per_sample = t / n
+    # sample chunks sized so that the im2col temporary of the contraction stays <= 8 GB (lets BLAS see a
+    # large GEMM); chunk = 1 beside it; the faster of the two is the baseline
+    im2col = 4.0 * float(np.prod(cfg['D'])) * cfg['M'] * float(np.prod(cfg['A'])) * max(1, cfg['C'])
+    chunk8 = int(max(1, min(cfg['N'], (8 << 30) // im2col)))
+    t1 = run(1, 1)
+    n = int(max(1, min(32, (budget_s / 2) // max(t1, 1e-3))))   # ~budget_s / 2 seconds of host work per variant
+    per_sample_1 = (run(n, 1) if n > 1 else t1) / n
+    tried = {'chunk=1': per_sample_1}
+    if chunk8 > 1:
+        n8 = max(chunk8, (n // chunk8) * chunk8)
+        tried[f'chunk={chunk8} (im2col <= 8 GB)'] = run(n8, chunk8) / n8
+    how, per_sample = min(tried.items(), key=lambda kv: kv[1])
     its = 1.0 / (per_sample * cfg['N'])
 
     # second, stronger comparator: the reference's default backend 'numpy_fft' (FFT form restated in the oracle)
@@ -137,7 +161,8 @@ def cpu_baseline(cfg, budget_s=20.0):
     return {
         'value': its, 'unit': 'MU-iterations/sec', 'cores': os.cpu_count(), 'kind': 'port',
         'sample': f'{n} of {cfg["N"]} samples of the same workload, 1 MU iteration, float32, sample-chunked '
-                  f'(chunk=1; {per_sample:.2f} s/sample), scaled x{cfg["N"] / n:g}',
+                  f'({how}; {per_sample:.2f} s/sample), scaled x{cfg["N"] / n:g}',
+        'chunkings_s_per_sample': tried,
         'fft_variant': {'value': its_fft, 'unit': 'MU-iterations/sec',
                         'what': "FFT form of the same iteration (the reference's default 'numpy_fft' algorithm, "
                                 'scipy.fft with workers=-1)',
@@ -152,9 +177,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument('--samples', type=int, default=None, help='override samples per GPU (debug)')
-    ap.add_argument('--path', default='auto', choices=['auto', 'generic', 'mfma', 'fft', 'hybrid'])
+    ap.add_argument('--path', default='auto', choices=['auto', 'generic', 'mfma', 'split', 'fft', 'hybrid'])
+    ap.add_argument('--algorithm', default='full', choices=['full', 'cyclic'],
+                    help='full: full-batch MU iterations; cyclic: Cyclic-MU epochs over mini-batches (configs 4, 5)')
+    ap.add_argument('--batch-size', type=int, default=None, help='global mini-batch size of --algorithm cyclic '
+                    '(default: a quarter of the global sample count)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fft-variant', action='store_true', help='skip the extra timed legs on the other kernel families')
+    ap.add_argument('--no-parity', action='store_true', help='skip the parity leg against the float64 oracle')
+    ap.add_argument('--parity-samples', type=int, default=None)
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
 
@@ -208,6 +239,10 @@ def main():
         Lx = next((L for L in (32, 48, 64, 96, 144, 192, 288, 384, 576) if L >= Hs[1]), 0)
         t_bytes = 8.0 * n_local * cfg['M'] * Hs[0] * (Lx // 2 + 1)
 
+    # samples one kernel launch processes, as a fraction of the rank's samples (Cyclic-MU launches work on one batch)
+    batch_size_g = args.batch_size if args.batch_size else max(1, n_global // 4)
+    launch_scale = 1.0 if args.algorithm == 'full' else min(1.0, -(-batch_size_g // world) / n_local)
+
     def group_roofline(name, avg_ms, paths):
         """Roofline entry of one kernel group: matrix-core groups against the f32 MFMA rate with the algorithmic flops of
         the direct formulation, FFT-family groups against HBM with the streams that formulation must move per launch."""
@@ -215,10 +250,20 @@ def main():
         flops = {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}.get(name)
         if flops is None or not avg_ms:
             return None
+        flops *= launch_scale
+        if fam == 'split':
+            # what is executed: six bf16 MFMA products per algorithmic f32 product (3 x bf16 operand splits)
+            tf = 6 * flops / (avg_ms * 1e-3) / 1e12
+            rmw = launch_scale * (2 * h_bytes + 8.0 * n_local * cfg['C'] * float(np.prod(cfg['D']))) / (avg_ms * 1e-3) / 1e9
+            return {'kernel': name, 'family': fam, 'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': tf / PEAK_BF16_TFLOPS, 'flops_per_launch': 6 * flops,
+                    'avg_launch_ms': avg_ms, 'priced_as': 'bf16 MFMA flops executed = 6 x algorithmic (3 x bf16 splits)',
+                    'f32_equivalent_tflops': flops / (avg_ms * 1e-3) / 1e12,
+                    'hbm_gbs_alg': rmw, 'frac_hbm_peak': rmw / PEAK_HBM_GBS}
         if fam == 'fft':
             hybrid = paths.get('update_H') != 'fft'     # H changes outside the family: its row spectra are redone
-            streams = {'reconstruct': t_bytes + (0.5 * (h_bytes + t_bytes) if hybrid else 0.0),
-                       'update_H': 5 * t_bytes + 2 * h_bytes, 'grad_W': t_bytes}[name]
+            streams = launch_scale * {'reconstruct': t_bytes + (0.5 * (h_bytes + t_bytes) if hybrid else 0.0),
+                                      'update_H': 5 * t_bytes + 2 * h_bytes, 'grad_W': t_bytes}[name]
             gbs = streams / (avg_ms * 1e-3) / 1e9
             return {'kernel': name, 'family': fam, 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': gbs / PEAK_HBM_GBS, 'bytes_per_launch': streams, 'avg_launch_ms': avg_ms,
@@ -227,14 +272,27 @@ def main():
         return {'kernel': name, 'family': fam, 'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tf / PEAK_F32_TFLOPS, 'flops_per_launch': flops, 'avg_launch_ms': avg_ms}
 
-    def run_leg(path, pg):
-        """args.warmup untimed + args.steps timed MU iterations from the fixed start on kernel family `path`."""
+    batch_size = batch_size_g
+
+    def run_leg(path, pg, split=True):
+        """args.warmup untimed + args.steps timed steps from the fixed start on kernel family `path`.  A step is one
+        full-batch MU iteration, or (--algorithm cyclic) one Cyclic-MU epoch driven by the front end's epoch function."""
         np.random.seed(42)             # same W on every rank
         torch.cuda.manual_seed(4242 + rank)
         model = TransformInvariantNMF(n_atoms=cfg['M'], atom_shape=tuple(cfg['A']), backend='hip', device=device,
-                                      path=path, init='device', process_group=pg)
+                                      path=path, init='device', process_group=pg, split=split)
         model._initialize_matrices(V, keep_W=False)
         b = model._backend
+        if args.algorithm == 'cyclic':
+            batches = b.minibatch_slices(batch_size)
+            h_args = dict(sparsity=0., inhibition=0., cross_inhibition=0.)
+
+            def step():
+                model._epoch_cyclic(None, batches, h_args, 1.)
+        else:
+            def step():
+                model._update_H()
+                model._update_W()
 
         def fence():
             if pg is not None:
@@ -242,14 +300,12 @@ def main():
             torch.cuda.synchronize(device)
 
         for _ in range(args.warmup):
-            model._update_H()
-            model._update_W()
+            step()
         fence()
         b.start_timeline()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            model._update_H()
-            model._update_W()
+            step()
         fence()
         el = time.perf_counter() - t0
         paths = b.timeline_paths
@@ -266,21 +322,27 @@ def main():
     # Further legs (single GPU only): the same iterations from the same start on the other kernel families -- the
     # direct-vs-FFT crossover of BASELINE.json configs[4].
     variants = {}
-    main_family = 'hybrid' if set(paths.values()) >= {'fft', 'mfma'} else be.last_path
+    fams = set(paths.values())
+    main_family = ('hybrid' if 'fft' in fams and (fams & {'mfma', 'split'}) else be.last_path)
+    if 'split' in fams:
+        main_family += '+split' if main_family != 'split' else ''
     if world == 1 and not args.no_fft_variant and k == 2:
         W_main = nmf.W
-        for vpath, label in (('mfma', 'direct_variant'), ('fft', 'fft_variant')):
-            if vpath == main_family or args.path == vpath:
+        legs = [('mfma', 'direct_variant', True), ('fft', 'fft_variant', True)]
+        if 'split' in fams:
+            legs.insert(0, (args.path, 'exact_f32_variant', False))   # same dispatch, H update on the exact f32 MFMA
+        for vpath, label, vsplit in legs:
+            if vsplit and (vpath == main_family or args.path == vpath):
                 continue
             try:
-                m2, el2, spans2, paths2 = run_leg(vpath, None)
+                m2, el2, spans2, paths2 = run_leg(vpath, None, split=vsplit)
             except Exception as exc:  # noqa: BLE001   (family does not cover the shape)
                 variants[label] = {'error': repr(exc)[:200]}
                 continue
             ms2 = {name: float(np.mean(ms)) for name, ms in spans2.items()}
             variants[label] = {
                 'value': args.steps / el2, 'unit': 'MU-iterations/sec', 'ms_per_step': el2 / args.steps * 1e3,
-                'path': vpath, 'kernel_families': paths2, 'kernels_ms': ms2,
+                'path': vpath, 'split': vsplit, 'kernel_families': paths2, 'kernels_ms': ms2,
                 'what': 'same data, same start, same iteration count, every kernel group forced onto this family',
                 'W_max_rel_diff_vs_main': float(np.abs(m2.W - W_main).max() / np.abs(W_main).max()),
                 'energy_after_run': m2._energy_function(),
@@ -290,6 +352,37 @@ def main():
             del m2
             torch.cuda.empty_cache()
 
+    # parity leg: the other half of BASELINE.json's metric (outside the timed region, rank 0, single GPU)
+    parity = None
+    if world == 1 and not args.no_parity:
+        from oracle import tnmf_oracle as orc
+        # ~3.2 thread-seconds per config-3 sample and iteration for the float64 C oracle: keep the leg near 10-20 s
+        rel_cost = conv_flops(cfg, 1) / conv_flops(CONFIGS[3], 1)
+        n_par = args.parity_samples or int(max(2, min(8, 8 // max(1.0, rel_cost / 3))))
+        n_par = min(n_par, n_local)
+        its_par = 5
+        orc.set_threads(orc.default_threads(cap=64))
+        Vp = np.ascontiguousarray(V[:n_par])
+        np.random.seed(42)
+        mp_ = TransformInvariantNMF(n_atoms=cfg['M'], atom_shape=tuple(cfg['A']), backend='hip', device=device,
+                                    path=args.path)
+        mp_.fit(Vp, n_iterations=its_par, progress_callback=lambda *_: True)
+        np.random.seed(42)
+        ref = orc.OracleNMF(n_atoms=cfg['M'], atom_shape=tuple(cfg['A']), impl='c').fit(Vp.astype(np.float64),
+                                                                                       n_iterations=its_par)
+        E_ref = ref.energy()
+        parity = {
+            'samples': n_par, 'iterations': its_par, 'path': args.path,
+            'reference': 'float64 C oracle (oracle/tnmf_oracle_c.c, pinned to the reference), same seeds '
+                         '(np.random.seed(42), H drawn before W), same first samples of the workload',
+            'W_rel_diff_vs_oracle': float(np.abs(mp_.W - ref.W).max() / np.abs(ref.W).max()),
+            'H_rel_diff_vs_oracle': float(np.abs(mp_.H - ref.H).max() / np.abs(ref.H).max()),
+            'energy_gap_vs_oracle': float(abs(mp_._energy_function() - E_ref) / E_ref),
+            'energy_oracle': float(E_ref),
+        }
+        del mp_, ref
+        torch.cuda.empty_cache()
+
     if rank == 0:
         kernels = {}
         for name, ms in spans.items():
@@ -298,7 +391,7 @@ def main():
         rl = {name: group_roofline(name, kernels[name]['avg_ms'], paths) for name in kernels}
         rl = {n: r for n, r in rl.items() if r}
         for n, r in rl.items():
-            kernels[n]['tflops_direct_equivalent'] = {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}[n] / (kernels[n]['avg_ms'] * 1e-3) / 1e12
+            kernels[n]['direct_equivalent_tflops'] = launch_scale * {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}[n] / (kernels[n]['avg_ms'] * 1e-3) / 1e12
         dom = max(rl, key=lambda n: kernels[n]['total_ms'])
         ms_per_step = elapsed / args.steps * 1e3
         roof = dict(rl[dom])
@@ -308,18 +401,26 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
-                'workload': f'2-D shift-invariant MU, full batch: {n_local} samples x {cfg["C"]} ch x '
+                'workload': (f'2-D shift-invariant MU, full batch: ' if args.algorithm == 'full' else
+                             f'2-D shift-invariant MU, Cyclic-MU epochs (global batch {batch_size}): ') +
+                            f'{n_local} samples x {cfg["C"]} ch x '
                             f'{"x".join(map(str, cfg["D"]))} per GPU, {cfg["M"]} atoms '
                             f'{"x".join(map(str, cfg["A"]))} (BASELINE.json configs[{args.config - 1}])',
                 'samples_per_gpu': n_local, 'global_samples': n_global, 'path': args.path, 'kernel_path': main_family,
-                'kernel_families': paths,
+                'kernel_families': paths, 'algorithm': args.algorithm,
+                'batch_size': batch_size if args.algorithm == 'cyclic' else None,
+                'h_update_arithmetic': ('3 x bf16 operand splits on the bf16 matrix cores (float32-grade; parity '
+                                        'object and exact_f32_variant beside it)' if 'split' in fams else
+                                        'exact f32' if paths.get('update_H') in ('mfma', 'generic') else 'fft'),
                 'parallelism': f'sample-sharded x{world}, all-reduce of W num/den per iteration' if world > 1 else 'single GPU',
                 'value_definition': 'shard-iterations completed by all ranks / max-over-ranks wall time',
                 'energy_after_run': energy,
             },
             'iteration': {
-                'flops_alg': 6 * F, 'bytes_alg': alg_bytes(cfg, n_local),
-                'tflops': 6 * F / (ms_per_step * 1e-3) / 1e12, 'frac_f32_peak': 6 * F / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+                # the direct formulation's flop count divided by this run's time: a cross-family yardstick, NOT a
+                # roofline fraction (the FFT family executes a fraction of these flops, the split kernel 6x bf16 ones)
+                'direct_equivalent_flops': 6 * F, 'bytes_alg': alg_bytes(cfg, n_local),
+                'direct_equivalent_tflops': 6 * F / (ms_per_step * 1e-3) / 1e12,
                 'hbm_gbs_alg': alg_bytes(cfg, n_local) / (ms_per_step * 1e-3) / 1e9,
                 'frac_hbm_peak': alg_bytes(cfg, n_local) / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
@@ -328,6 +429,10 @@ def main():
             'roofline_by_kernel': rl,
         }
         line.update(variants)
+        if parity is not None:
+            line['parity'] = parity
+            line['energy_gap_vs_oracle'] = parity['energy_gap_vs_oracle']
+            line['W_rel_diff_vs_oracle'] = parity['W_rel_diff_vs_oracle']
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, args.cpu_budget)
             line['cpu_baseline']['gpu_over_cpu'] = line['value'] / line['cpu_baseline']['value']

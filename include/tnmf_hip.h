@@ -13,6 +13,10 @@
  *   - element type: geom.dtype 0 = float32, 1 = float64.  'valid' reconstruction mode only:
  *       V[N,C,*D]  W[M,C,*A]  H[N,M,*(D+A-1)]  R[N,C,*D];   ndim = 1 or 2 shift axes.
  *   - mini-batch slices are contiguous along the sample axis: the caller offsets V/H/R pointers and passes the slice's N.
+ *   - one context = one device.  SURVEY.md 8b sketched a multi-device context (tnmf_hip_ctx_create(device_ids[], n)) and
+ *     an in-library tnmf_hip_allreduce_negpos; this library deliberately has neither: the product runs one process per
+ *     GPU and the single collective of the path -- the sum of the [neg | pos] buffer of tnmf_hip_grad_W_fused -- is done
+ *     by the caller between tnmf_hip_grad_W_fused and tnmf_hip_apply_W (torch.distributed / RCCL in tnmf_amd/backends/HIP.py).
  *   - calls on one ctx are not thread-safe; different ctxs are independent.  All launches are asynchronous on
  *     `stream` except tnmf_hip_energy, which synchronises the stream to return its scalar.
  */
@@ -25,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TNMF_HIP_ABI_VERSION 2
+#define TNMF_HIP_ABI_VERSION 3
 
 enum {
     TNMF_OK = 0,
@@ -52,13 +56,21 @@ typedef struct {
  * problems with at least 2^19 activation entries, the HYBRID dispatch described below.  FFT is the
  * frequency-domain formulation (the algorithm of the reference's default backend, tnmf/backends/NumPy_FFT.py:16-40):
  * float32 2-D problems with shift shapes up to 576, float64 up to 144. */
-enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_FFT = 3, TNMF_PATH_HYBRID = 4 };
+enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_FFT = 3, TNMF_PATH_HYBRID = 4,
+       TNMF_PATH_SPLIT = 5 };
 /* HYBRID: reconstruct and the W gradient on the FFT family (their float32 transform error is benign: R has no small
  * entries, the W gradient is a sum over all samples), the H gradient / fused H update on the direct kernels (exact
  * summation of the few-tap border entries).  Falls back to AUTO where the FFT family does not cover the shape.
  * The FFT family (under FFT and HYBRID alike) assumes non-negative factors: R and the W gradient are clamped at zero
  * from below, which only removes transform rounding noise (V, W, H >= 0 imply both >= 0) and keeps the denominators
  * of the multiplicative updates non-negative. */
+
+/* SPLIT: the direct kernels, with the H gradient / fused H update on the bf16 matrix cores: every float32 operand is
+ * split exactly into three bf16 terms and a product is the sum of the six term products of weight >= 2^-16 -- float32-grade
+ * results (error against a float64 reference no larger than the f32 MFMA chain's) at 16/6 of the f32 matrix rate.
+ * MFMA keeps every kernel on the exact f32-input MFMA (a k-ordered fmaf chain).  AUTO and HYBRID use the split H update
+ * where it covers the shape (float32, 2-D, atoms up to 16 x 16) unless tnmf_hip_ctx_set_split(ctx, 0) turned it off. */
+int tnmf_hip_ctx_set_split(tnmf_hip_ctx *ctx, int enable);
 
 int tnmf_hip_abi_version(void);
 const char *tnmf_hip_strerror(int code);
@@ -69,7 +81,7 @@ int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx);
 /* Pre-size the scratch for `geom` so that later calls allocate nothing (graph-capture safe). */
 int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom);
 int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path);
-/* Name of the kernel family the last primitive call on this ctx dispatched to ("generic", "mfma", "fft"). */
+/* Name of the kernel family the last primitive call on this ctx dispatched to ("generic", "mfma", "split", "fft"). */
 const char *tnmf_hip_ctx_last_path(const tnmf_hip_ctx *ctx);
 /* FFT family only: the library may keep the row spectra of the activations H it transformed or updated last, and the
  * spectra of the samples V it transformed last, and reuse them while the same pointers and geometry come back (the

@@ -52,3 +52,50 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith(('.py', '.hip', '.h')):
                 assert not pat.search(open(os.path.join(dirpath, f)).read()), f
+
+
+def test_product_library_has_no_diagnostic_switches():
+    """Phase ablation, cycle stamps and forced kernel variants exist only in -DTNMF_DIAG builds (make DIAG=1): the
+    product library must not look at the environment at all."""
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    for name in (b'TNMF_HIP_ABLATE', b'TNMF_HIP_STAMPS', b'TNMF_FFT_NO_MIXED', b'TNMF_FFT_NO_RESIDENT',
+                 b'TNMF_MIX_GROUPS', b'TNMF_FFT_WINDOW_MB'):
+        assert name not in blob, name
+    import subprocess
+    syms = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'getenv' not in syms
+
+
+def test_array_contract_of_the_reference_front_end_on_torch_tensors():
+    """which of the array-object operations the REFERENCE front end applies to backend-native
+    arrays (tnmf/TransformInvariantNMF.py:232-235, :271, :447-453, :458, :483, :258-268) a torch.Tensor
+    satisfies.  CPU tensors stand in for ROCm tensors: the operator semantics are the same, only `tensor - ndarray`
+    additionally fails for a device tensor."""
+    import numpy as np
+    import torch
+    H = torch.rand(4, 3, 9, dtype=torch.float64)
+    neg, pos = torch.rand_like(H), torch.rand_like(H)
+    s = slice(1, 3)
+    view = H[s]
+    assert view.data_ptr() == H[1].data_ptr()           # H[s] is a writable view (:271)
+    pos += 1e-9                                         # += Python float (:232)
+    before = H.clone()
+    view *= neg[s]                                      # in-place *=, /= with same-type arrays (:234-235)
+    view /= pos[s]
+    assert not torch.equal(H[s], before[s]) and torch.equal(H[0], before[0])
+    acc = 0 + neg                                       # 0 + arr start values (:458, :483)
+    acc += pos                                          # += arrays (:447-448)
+    acc *= 0.8                                          # *= float (:450-451)
+    acc += 0.2 * neg                                    # float * arr (:452-453)
+    assert acc.shape == H.shape
+    g = -H                                              # inhibition branch (:258-268): -arr, .sum(axis=1, keepdims=True)
+    assert g.sum(axis=1, keepdims=True).shape == (4, 1, 9)
+    # `inhibition_gradient - self.H[s]` (:258) subtracts the NDARRAY property self.H from a backend-native array.  A CPU
+    # tensor takes that (the reference's own PyTorch backends rely on it); a ROCm tensor raises TypeError (GPU test
+    # tests/test_hip_scale.py::test_reference_inhibition_line_needs_backend_native_H), so under the reference's
+    # UNMODIFIED front end the inhibition terms need a one-line change (self._H[s] in place of self.H[s]) -- stated in
+    # INTEGRATION.md section 2.  This repository's front end uses the backend-native H (TransformInvariantNMF.py:170).
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', DeprecationWarning)
+        assert isinstance(H - np.zeros(H.shape), torch.Tensor)

@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libtnmf_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/tnmf_hip.h declares
 EXPORTS = (
@@ -20,11 +20,12 @@ EXPORTS = (
     'tnmf_hip_grad_H', 'tnmf_hip_grad_W', 'tnmf_hip_mu_update', 'tnmf_hip_normalize_W', 'tnmf_hip_energy',
     'tnmf_hip_convolve_multi_1d', 'tnmf_hip_update_H', 'tnmf_hip_grad_W_fused', 'tnmf_hip_apply_W',
     'tnmf_hip_pad_H', 'tnmf_hip_fold_H', 'tnmf_hip_ctx_set_cache', 'tnmf_hip_ctx_invalidate',
+    'tnmf_hip_ctx_set_split',
 )
 
 MODES = {'valid': 0, 'full': 1, 'circular': 2, 'reflect': 3}
 
-PATHS = {'auto': 0, 'generic': 1, 'mfma': 2, 'fft': 3, 'hybrid': 4}
+PATHS = {'auto': 0, 'generic': 1, 'mfma': 2, 'fft': 3, 'hybrid': 4, 'split': 5}
 
 
 class Geom(ctypes.Structure):
@@ -65,6 +66,7 @@ def load() -> ctypes.CDLL:
     lib.tnmf_hip_ctx_reserve.argtypes = [vp, gp]
     lib.tnmf_hip_ctx_set_path.argtypes = [vp, ci]
     lib.tnmf_hip_ctx_set_cache.argtypes = [vp, ci]
+    lib.tnmf_hip_ctx_set_split.argtypes = [vp, ci]
     lib.tnmf_hip_ctx_invalidate.argtypes = [vp]
     lib.tnmf_hip_ctx_last_path.restype = ctypes.c_char_p
     lib.tnmf_hip_ctx_last_path.argtypes = [vp]

@@ -12,6 +12,8 @@ backend reproduces) and tnmf/backends/_Backend.py (the interface).
 from typing import Optional, Sequence, Tuple
 
 import ctypes
+import weakref
+
 import numpy as np
 import torch
 
@@ -56,17 +58,24 @@ class HIP_Backend(Backend):
            pad the activations (tnmf_hip_pad_H), run the same 'valid' kernels on the padded tensor and fold the H gradient
            back (tnmf_hip_fold_H) -- the padding table of the reference's _PyTorchBackend.py:42-52
     device : CUDA/HIP device index or ``torch.device``; default: the current device
-    path : ``'auto'`` | ``'generic'`` | ``'mfma'`` | ``'fft'`` -- kernel family (``'auto'`` = MFMA where the shape
-           allows; ``'fft'`` = frequency-domain formulation, the algorithm of the reference's default backend)
+    path : ``'auto'`` | ``'generic'`` | ``'mfma'`` | ``'split'`` | ``'fft'`` | ``'hybrid'`` -- kernel family
+           (``'auto'`` = the fastest dispatch that keeps W and H within 1e-5 of the float64 reference; ``'mfma'`` = direct
+           kernels on the exact f32-input MFMA; ``'split'`` = direct kernels with the H update on the bf16 matrix
+           cores through exact 3 x bf16 operand splits; ``'fft'`` = frequency-domain formulation, the algorithm of the
+           reference's default backend; ``'hybrid'`` = FFT family for reconstruct and the W gradient, direct H update)
+    split : ``True`` (default) lets ``'auto'`` / ``'hybrid'`` run the H update on the bf16 matrix cores (3 x bf16 splits,
+           float32-grade); ``False`` keeps it on the exact f32-input MFMA
     init : ``'reference'`` draws H then W from the global legacy NumPy RNG exactly like the reference
            (_Backend.py:92-95); ``'device'`` draws them with the device generator (fast, not seed-compatible)
-    process_group : a ``torch.distributed`` group, ``True`` for the default group, or ``None``.  With a group the
-           sample axis is sharded in contiguous blocks over the ranks: this rank keeps V[n0:n1] and H[n0:n1], the
-           W-gradient numerator/denominator is all-reduced (sum) before it is returned, the energy likewise.
+    process_group : a ``torch.distributed`` group, ``True`` for the default group, ``None``, or any object with
+           ``rank``, ``world_size`` and ``all_reduce_sum(tensor)`` (a collective injected by the caller; the tests use
+           an in-process one to run two ranks on one GPU).  With a group the sample axis is sharded in contiguous blocks
+           over the ranks: this rank keeps V[n0:n1] and H[n0:n1], the W-gradient numerator/denominator is all-reduced
+           (sum) before it is returned, the energy likewise.
     """
 
     def __init__(self, reconstruction_mode: str = 'valid', device=None, path: str = 'auto', init: str = 'reference',
-                 process_group=None):
+                 process_group=None, split: bool = True):
         if reconstruction_mode not in _lib.MODES:
             raise ValueError(f'Unsupported reconstruction mode "{reconstruction_mode}". '
                              f'Please choose "valid", "full", "circular", or "reflect".')
@@ -84,17 +93,23 @@ class HIP_Backend(Backend):
         self._ctx = ctypes.c_void_p()
         _lib.check(self._lib.tnmf_hip_ctx_create(self._device.index, ctypes.byref(self._ctx)), 'tnmf_hip_ctx_create')
         _lib.check(self._lib.tnmf_hip_ctx_set_path(self._ctx, _lib.PATHS[path]), 'tnmf_hip_ctx_set_path')
+        _lib.check(self._lib.tnmf_hip_ctx_set_split(self._ctx, 1 if split else 0), 'tnmf_hip_ctx_set_split')
         # FFT family: the library may reuse the row spectra of H between the fused half steps (it updated H itself);
         # every other entry point below declares H as possibly changed first (_foreign_H).
         _lib.check(self._lib.tnmf_hip_ctx_set_cache(self._ctx, 1 if reconstruction_mode == 'valid' else 0),
                    'tnmf_hip_ctx_set_cache')
 
         self._group = None
+        self._collective = None     # injected: object with rank / world_size / all_reduce_sum(tensor)
         self._rank, self._world = 0, 1
         if process_group is not None and process_group is not False:
-            import torch.distributed as dist
-            self._group = dist.group.WORLD if process_group is True else process_group
-            self._rank, self._world = dist.get_rank(self._group), dist.get_world_size(self._group)
+            if hasattr(process_group, 'all_reduce_sum'):
+                self._collective = process_group
+                self._rank, self._world = int(process_group.rank), int(process_group.world_size)
+            else:
+                import torch.distributed as dist
+                self._group = dist.group.WORLD if process_group is True else process_group
+                self._rank, self._world = dist.get_rank(self._group), dist.get_world_size(self._group)
 
         self._torch_dtype = None
         self._dtype_code = None
@@ -104,6 +119,7 @@ class HIP_Backend(Backend):
         self._negpos = None
         self._timeline = None
         self._timeline_paths = {}
+        self._cached_H = None       # (weakref of the base tensor, data_ptr, shape, torch version counter)
 
     def __del__(self):
         try:
@@ -130,6 +146,32 @@ class HIP_Backend(Backend):
     def _foreign_H(self) -> None:
         """H of the coming call may have been written by someone else: drop cached spectra (FFT family)."""
         self._lib.tnmf_hip_ctx_invalidate(self._ctx)
+        self._cached_H = None
+
+    # The FFT family may keep the row spectra of the activations it transformed or updated last
+    # (tnmf_hip_ctx_set_cache); the library can only key that cache on the raw pointer.  Validity is therefore owned
+    # HERE: after each fused call the identity of the tensor (weak reference to its base), its pointer, shape and
+    # torch's version counter are recorded; a fused call whose H does not match -- another tensor at the same address,
+    # or the same tensor written by any torch operation in between (which bumps the counter; the library's own writes
+    # through the raw pointer do not) -- invalidates first.
+    @staticmethod
+    def _h_key(Hs: torch.Tensor):
+        base = Hs._base if Hs._base is not None else Hs
+        return base, (Hs.data_ptr(), tuple(Hs.shape), base._version)
+
+    def _validate_H_cache(self, Hs: torch.Tensor) -> None:
+        c = self._cached_H
+        if c is None:
+            self._lib.tnmf_hip_ctx_invalidate(self._ctx)
+            return
+        base, key = self._h_key(Hs)
+        if c[0]() is not base or c[1] != key:
+            self._lib.tnmf_hip_ctx_invalidate(self._ctx)
+            self._cached_H = None
+
+    def _note_H_cache(self, Hs: torch.Tensor) -> None:
+        base, key = self._h_key(Hs)
+        self._cached_H = (weakref.ref(base), key)
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
@@ -214,7 +256,10 @@ class HIP_Backend(Backend):
         return G
 
     def _all_reduce(self, t: torch.Tensor) -> None:
-        sharding.all_reduce_sum(t, self._group)
+        if self._collective is not None:
+            self._collective.all_reduce_sum(t)
+        else:
+            sharding.all_reduce_sum(t, self._group)
 
     # -- set-up ---------------------------------------------------------------------------------------------
     def _initialize_matrices(self, V: np.ndarray, atom_shape, n_atoms: int, W=None, axes_W_normalization=None):
@@ -286,6 +331,8 @@ class HIP_Backend(Backend):
         Hs, Vs = H[ls], self._V_dev[ls]
         self._check_W(W)
         self._check_H(Hs, W.shape[0])
+        if self._mode == 0:
+            self._validate_H_cache(Hs)
         Hs = self._pad(Hs)
         negpos = torch.empty_like(self._negpos)
         g = self._geom(Hs.shape[0], W.shape[0])
@@ -300,6 +347,8 @@ class HIP_Backend(Backend):
             _lib.check(self._lib.tnmf_hip_grad_W_fused(self._ctx, ctypes.byref(g), _ptr(Vs), _ptr(W), _ptr(Hs),
                                                        _ptr(Rs), r_valid, _ptr(negpos), self._stream()),
                        'tnmf_hip_grad_W_fused')
+        if self._mode == 0 and Hs.shape[0]:
+            self._note_H_cache(Hs)
         return negpos
 
     def reconstruction_gradient_W(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone):
@@ -390,6 +439,7 @@ class HIP_Backend(Backend):
         g = self._geom(Hs.shape[0], W.shape[0])
         Rs = self._R_scratch[ls]
         r_valid = 0
+        self._validate_H_cache(Hs)
         if self._timeline is not None:
             with self._timed('reconstruct'):
                 _lib.check(self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(Hs), _ptr(Rs),
@@ -399,6 +449,7 @@ class HIP_Backend(Backend):
             _lib.check(self._lib.tnmf_hip_update_H(self._ctx, ctypes.byref(g), _ptr(Vs), _ptr(W), _ptr(Hs), _ptr(Rs),
                                                    r_valid, float(eps), float(sparsity), self._stream()),
                        'tnmf_hip_update_H')
+        self._note_H_cache(Hs)
 
     def apply_W(self, W: torch.Tensor, negpos: torch.Tensor, eps: float = 1e-9) -> None:
         """W = W * neg / (pos + eps), then normalise over the atom axes (TransformInvariantNMF.py:232-238)."""

@@ -7,6 +7,7 @@
 #include "fft.h"
 #include "generic.h"
 #include "mfma.h"
+#include "split.h"
 
 namespace {
 
@@ -95,6 +96,14 @@ bool use_fft_hybrid(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
     return (size_t)g.N * g.M * g.Hy * g.Hx >= ((size_t)1 << 19);
 }
 
+// H gradient on the bf16 matrix cores with exact 3 x bf16 operand splits: forced by TNMF_PATH_SPLIT, default under AUTO
+// and HYBRID (tnmf_hip_ctx_set_split), never under MFMA (the exact-f32 family), GENERIC or FFT.
+bool use_split(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
+    if (ctx->path == TNMF_PATH_SPLIT) return split_has_corr_W(g, dtype);
+    if (ctx->path != TNMF_PATH_AUTO && ctx->path != TNMF_PATH_HYBRID) return false;
+    return ctx->split && split_has_corr_W(g, dtype);
+}
+
 bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
     if (ctx->path == TNMF_PATH_GENERIC || ctx->path == TNMF_PATH_FFT) return false;   // (FFT never gets here)
     switch (prim) {
@@ -144,12 +153,18 @@ int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const v
     if (ctx->path == TNMF_PATH_FFT)
         return fused ? fft_update_H(ctx, g, dtype, V, R, W, Hio, reg, s) : fft_grad_H(ctx, g, dtype, V, R, W, neg, pos, s);
     if (fused) fft_invalidate_H(ctx);   // the direct kernels are about to change H: cached row spectra are stale
+    if (use_split(ctx, g, dtype)) {
+        const int rc = split_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio,
+                                    (float *)neg, (float *)pos, fused, (float)reg, s);
+        if (rc == TNMF_OK) ctx->last_path = "split";
+        if (rc != TNMF_E_UNSUPPORTED) return rc;
+    }
     if (use_mfma(ctx, g, dtype, kCorrW)) {
         ctx->last_path = "mfma";
         return mfma_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio, (float *)neg,
                            (float *)pos, fused, (float)reg, s);
     }
-    if (ctx->path == TNMF_PATH_MFMA) return TNMF_E_UNSUPPORTED;
+    if (ctx->path == TNMF_PATH_MFMA || ctx->path == TNMF_PATH_SPLIT) return TNMF_E_UNSUPPORTED;
     ctx->last_path = "generic";
     return generic_corr_W(ctx, g, dtype, V, R, W, Hio, neg, pos, fused, reg, s);
 }
@@ -207,6 +222,11 @@ int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out) {
     TNMF_HIP_TRY(hipSetDevice(device_id));
     hipDeviceProp_t prop;
     TNMF_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    {
+        int rc = mfma_prepare_device();   // per device, hence per context
+        if (rc == TNMF_OK) rc = split_prepare_device();
+        if (rc != TNMF_OK) return rc;
+    }
     tnmf_hip_ctx *ctx = new (std::nothrow) tnmf_hip_ctx();
     if (!ctx) return TNMF_E_WORKSPACE;
     ctx->device = device_id;
@@ -214,11 +234,14 @@ int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out) {
     ctx->path = TNMF_PATH_AUTO;
     ctx->last_path = "none";
     {
-        const char *ab = getenv("TNMF_HIP_ABLATE");   // diagnostic builds of the timing harness only
+        const char *ab = tnmf_diag_env("TNMF_HIP_ABLATE");   // -DTNMF_DIAG builds only; nullptr in the product
         ctx->ablate = ab ? atoi(ab) : 0;
     }
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
+    ctx->split = 1;
+    ctx->wimg = nullptr;
+    ctx->wimg_bytes = 0;
     ctx->fft = FftState();
     *out = ctx;
     return TNMF_OK;
@@ -227,11 +250,12 @@ int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out) {
 int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx) {
     if (!ctx) return TNMF_OK;
     int rc = TNMF_OK;
-    if (ctx->ws || ctx->fft.ws) {
+    if (ctx->ws || ctx->fft.ws || ctx->wimg) {
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
     }
     fft_release(ctx);
+    split_release(ctx);
     if (ctx->ws) {
         const hipError_t e = hipFree(ctx->ws);
         if (e != hipSuccess) rc = (int)e;
@@ -254,8 +278,14 @@ int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom) {
 
 int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path) {
     if (!ctx) return TNMF_E_NULL;
-    if (path < TNMF_PATH_AUTO || path > TNMF_PATH_HYBRID) return TNMF_E_UNSUPPORTED;
+    if (path < TNMF_PATH_AUTO || path > TNMF_PATH_SPLIT) return TNMF_E_UNSUPPORTED;
     ctx->path = path;
+    return TNMF_OK;
+}
+
+int tnmf_hip_ctx_set_split(tnmf_hip_ctx *ctx, int enable) {
+    if (!ctx) return TNMF_E_NULL;
+    ctx->split = enable != 0;
     return TNMF_OK;
 }
 

@@ -19,6 +19,7 @@ struct Geo {
 struct FftState {
     void *ws;
     size_t ws_bytes;
+    size_t failed_bytes;     // smallest workspace request that hipMalloc has refused (0: none); sticky until release
     bool cache_enabled;      // the caller vouches that H and V only change through this library or are announced
                              // with tnmf_hip_ctx_invalidate (tnmf_hip_ctx_set_cache)
     bool T_valid;            // the workspace holds the row spectra of T_owner for T_geo / T_dtype
@@ -38,11 +39,27 @@ struct tnmf_hip_ctx {
     int num_cu;
     int path;               // TNMF_PATH_*
     const char *last_path;  // "generic" | "mfma" | "fft"
-    int ablate;             // diagnostic only (env TNMF_HIP_ABLATE at ctx creation): kernels skip phases; results wrong
+    int ablate;             // always 0 in the product build; -DTNMF_DIAG builds (tools/probes) read env TNMF_HIP_ABLATE
     void *ws;               // scratch: [R | split-K partials | reduction words]
     size_t ws_bytes;
+    int split;              // 1: the H gradient may run on the bf16 matrix cores with 3 x bf16 operand splits (split.hip)
+    void *wimg;             // pre-split register images of W for split.hip
+    size_t wimg_bytes;
     FftState fft;
 };
+
+// Diagnostic switches (phase ablation, cycle stamps, forced kernel variants) exist only in -DTNMF_DIAG builds, which
+// the timing probes under tools/probes/ make for themselves (`make DIAG=1`, output libtnmf_hip_diag.so).  The product
+// library reads no environment variable: TNMF_ABL() folds every ablation test to a compile-time 0 and
+// tnmf_diag_env() to "unset".
+#ifdef TNMF_DIAG
+#include <stdlib.h>
+#define TNMF_ABL(x) (x)
+static inline const char *tnmf_diag_env(const char *name) { return getenv(name); }
+#else
+#define TNMF_ABL(x) 0
+static inline const char *tnmf_diag_env(const char *) { return nullptr; }
+#endif
 
 #define TNMF_HIP_TRY(expr)                          \
     do {                                            \

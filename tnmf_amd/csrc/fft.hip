@@ -74,7 +74,7 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
     // the budget allows.
     const size_t per_sample = (size_t)2 * g.M * g.Hy * kxp * c;
     size_t budget = (size_t)8 << 30;
-    if (const char *e = getenv("TNMF_FFT_WINDOW_MB")) budget = (size_t)atol(e) << 20;
+    if (const char *e = tnmf_diag_env("TNMF_FFT_WINDOW_MB")) budget = (size_t)atol(e) << 20;
     long chunk = (long)(budget / per_sample);
     if (chunk < 1) chunk = 1;
     if (chunk > g.N) chunk = g.N > 0 ? g.N : 1;
@@ -124,20 +124,25 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
 int ensure_ws(tnmf_hip_ctx *ctx, size_t bytes) {
     FftState &f = ctx->fft;
     if (bytes <= f.ws_bytes) return TNMF_OK;
+    // A request at least as large as one that already failed is refused at once: under TNMF_PATH_AUTO the callers fall
+    // back to the direct kernels, and must not pay a multi-GB hipMalloc attempt on every call.
+    if (f.failed_bytes && bytes >= f.failed_bytes) return TNMF_E_WORKSPACE;
+    // the larger buffer is allocated BEFORE the current one is released, so a failure leaves the working one in place
+    const size_t want = align_up(bytes, 1 << 20);
+    void *bigger = nullptr;
+    if (hipMalloc(&bigger, want) != hipSuccess) {
+        (void)hipGetLastError();
+        f.failed_bytes = bytes;
+        return TNMF_E_WORKSPACE;
+    }
     if (f.ws) {
         TNMF_HIP_TRY(hipDeviceSynchronize());
         TNMF_HIP_TRY(hipFree(f.ws));
-        f.ws = nullptr;
-        f.ws_bytes = 0;
     }
+    f.ws = bigger;
+    f.ws_bytes = want;
     f.T_valid = f.SH_valid = false;
     f.V_valid = f.SV_valid = false;
-    const size_t want = align_up(bytes, 1 << 20);
-    if (hipMalloc(&f.ws, want) != hipSuccess) {
-        (void)hipGetLastError();
-        return TNMF_E_WORKSPACE;
-    }
-    f.ws_bytes = want;
     return TNMF_OK;
 }
 
@@ -218,12 +223,12 @@ int forward_planes(const Geo &g, const Lay &l, int dtype, const void *src, int p
 }
 
 bool use_mixed(const Geo &g, int dtype, bool grad_W) {
-    static const bool off = getenv("TNMF_FFT_NO_MIXED") != nullptr;   // diagnostic: force the column-transform kernels
+    static const bool off = tnmf_diag_env("TNMF_FFT_NO_MIXED") != nullptr;   // diagnostic: force the column-transform kernels
     return !off && (grad_W ? mixed_has_grad_W(g, dtype) : mixed_has_reconstruct(g, dtype));
 }
 
 bool use_resident(const Lay &l) {
-    static const bool off = getenv("TNMF_FFT_NO_RESIDENT") != nullptr;   // diagnostic: contract inside the column kernels
+    static const bool off = tnmf_diag_env("TNMF_FFT_NO_RESIDENT") != nullptr;   // diagnostic: contract inside the column kernels
     return l.resident && !off;
 }
 
@@ -384,6 +389,7 @@ void fft_release(tnmf_hip_ctx *ctx) {
     if (ctx->fft.ws) (void)hipFree(ctx->fft.ws);
     ctx->fft.ws = nullptr;
     ctx->fft.ws_bytes = 0;
+    ctx->fft.failed_bytes = 0;
     ctx->fft.T_valid = ctx->fft.SH_valid = false;
     ctx->fft.V_valid = false;
     ctx->fft.SV_valid = false;
@@ -524,7 +530,8 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
         // transform along x only; the Ay lags along y are accumulated directly (fft_mixed.hip)
         CHECK(forward_rows(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.RT), s));
         int ng_want = 32;
-        if (const char *e = getenv("TNMF_MIX_GROUPS")) ng_want = atoi(e);
+        if (const char *e = tnmf_diag_env("TNMF_MIX_GROUPS")) ng_want = atoi(e);   // diagnostic builds only
+        ng_want = ng_want < 1 ? 1 : (ng_want > 32 ? 32 : ng_want);                 // Gn/Gp hold 32 groups
         int ng = g.N < ng_want ? g.N : ng_want;
         const int nper = cdiv(g.N, ng);
         ng = cdiv(g.N, nper);

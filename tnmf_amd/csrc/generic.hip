@@ -629,6 +629,9 @@ int launch_pad_fold(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, int mode, 
                     hipStream_t s) {
     const int Sy = g.Dy == 1 && g.Ay == 1 ? 1 : mode_shift(g.Dy, g.Ay, mode), Sx = mode_shift(g.Dx, g.Ax, mode);
     if (Sy < 1 || Sx < 1 || g.Ay - 1 > Sy || g.Ax - 1 > Sx) return TNMF_E_GEOM;
+    // 'reflect' mirrors without repeating the edge: a pad of A-1 needs A-1 < S (torch's reflect pad raises otherwise,
+    // _PyTorchBackend.py:42-52 / torch.nn.functional.pad); pad == S would read one element past the activation row
+    if (mode == TNMF_MODE_REFLECT && (g.Ay - 1 >= Sy || g.Ax - 1 >= Sx)) return TNMF_E_GEOM;
     const size_t rows = (size_t)g.N * g.M;
     const size_t total = rows * (fold ? (size_t)Sy * Sx : (size_t)g.Hy * g.Hx);
     if (total == 0) return TNMF_OK;

@@ -12,3 +12,5 @@ int mfma_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R,
 int mfma_corr_H_chunks(const tnmf_hip_ctx *ctx, const Geo &g);
 int mfma_corr_H(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *H, double *partials,
                 int P, hipStream_t s);
+// sets the per-device kernel attributes (dynamic LDS above 64 KB); call once per context after hipSetDevice
+int mfma_prepare_device();

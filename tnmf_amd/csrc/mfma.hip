@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
         const float *v = V + ((size_t)n * g.C + c) * g.Dy * g.Dx;
         const float *r = Rr + ((size_t)n * g.C + c) * g.Dy * g.Dx;
         __syncthreads();
-        if (!(ablate & 1))
+        if (!(TNMF_ABL(ablate) & 1))
         for (int i = threadIdx.x; i < SH * CW_XSTR; i += kBlock) {
             const int rr = i / CW_XSTR, q = i - rr * CW_XSTR;
             const int y = u0 + rr - (g.Ay - 1), x = v0 + q - (g.Ax - 1);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
             const size_t o = (size_t)y * g.Dx + x;
             Xs[i] = in ? float2{v[o], r[o]} : float2{0.f, 0.f};
         }
-        if (!(ablate & 2))
+        if (!(TNMF_ABL(ablate) & 2))
         for (int i = threadIdx.x; i < KC * 32; i += kBlock) {
             const int kk = i >> 5, mi = i & 31;
             const int a = kk / Axp, b = kk - a * Axp;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
             ap[rb] = mfma32(w_, x_[rb].y, ap[rb]);            \
         }                                                     \
     } while (0)
-        if (ablate & 4) st = nsteps;
+        if (TNMF_ABL(ablate) & 4) st = nsteps;
         CW_LOAD(wA, xA);
         while (st + 2 <= nsteps) {
             CW_NEXT();
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W(Geo g, int tiles_y, i
     // half touch 128 contiguous bytes.  FUSED: the 16 H values of one tile row are loaded before the first store so that
     // the loads are independent: one memory round trip per tile row.  (Loading all four rows at once costs a wave of
     // occupancy and measured slower; see DESIGN.md.)
-    if (vv < g.Hx && !(ablate & 8)) {
+    if (vv < g.Hx && !(TNMF_ABL(ablate) & 8)) {
 #pragma unroll
         for (int rb = 0; rb < CW_RB; ++rb) {
             const int u = u0 + wave * CW_RB + rb;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
     const int my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int my_stages = my_tiles * g.C;
     (void)nstages;
-    if (my_stages > 0 && !(ablate & 1)) prefetch(0);
+    if (my_stages > 0 && !(TNMF_ABL(ablate) & 1)) prefetch(0);
 
     f32x16 an[CP_RB], ap[CP_RB];
     float hv[CP_RB][16];
@@ -343,16 +343,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
             }
         }
         lds_barrier();   // every wave is done with the previous window (and, first time, W is staged)
-        if (!(ablate & 1)) commit(st);
+        if (!(TNMF_ABL(ablate) & 1)) commit(st);
         lds_barrier();
-        if (st + 1 < my_stages && !(ablate & 1)) prefetch(st + 1);
+        if (st + 1 < my_stages && !(TNMF_ABL(ablate) & 1)) prefetch(st + 1);
         // D = [pixel][atom] (A operand = window, B operand = W): lane (atom = lane&31, hl = lane>>5) holds, per
         // accumulator, pixels 8q + 4hl + {0..3} in registers 4q..4q+3: four consecutive pixels of one atom = one 16-byte
         // access.  (The [atom][pixel] orientation needs 4x as many 4-byte store instructions and is store-issue bound.)
         const int atom = mt * 32 + j;
         const int atomc = atom < g.M ? atom : g.M - 1;
         const bool interior = v0 + CW_TX <= g.Hx;   // wave-uniform: whole tile inside the row
-        if (FUSED && c == g.C - 1 && !(ablate & (8 | 128))) {
+        if (FUSED && c == g.C - 1 && !(TNMF_ABL(ablate) & (8 | 128))) {
             // H values of this lane's outputs: clamped (always legal) addresses, consumed only in the epilogue
 #pragma unroll
             for (int rb = 0; rb < CP_RB; ++rb) {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
                 ap[rb] = mfma32(x_[q][rb].y, w_[q], ap[rb]);                                         \
             }                                                                                        \
     } while (0)
-            if (!(ablate & 4)) {
+            if (!(TNMF_ABL(ablate) & 4)) {
                 int a = 0;
                 CPR_LOAD(wA, xA, 0);
                 while (a + 2 <= g.Ay) {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
         } else {
         // k loop over (a, b-pair) of channel c, two operand register sets (see k_mfma_corr_W)
         const int nsteps = g.Ay * (Axp >> 1);
-        int b2 = 0, xo = 0, k = (ablate & 4) ? nsteps : 0;
+        int b2 = 0, xo = 0, k = (TNMF_ABL(ablate) & 4) ? nsteps : 0;
         float wA, wB;
         float2 xA[CP_RB], xB[CP_RB];
 #define CP_LOAD(w_, x_)                                                                      \
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_W_persist(Geo g, int ti
 #undef CP_MMA
         }
 
-        if (c == g.C - 1 && atom < g.M && !(ablate & (8 | 64))) {
+        if (c == g.C - 1 && atom < g.M && !(TNMF_ABL(ablate) & (8 | 64))) {
 #pragma unroll
             for (int rb = 0; rb < CP_RB; ++rb) {
                 const int u = u0 + wave * CP_RB + rb;
@@ -671,12 +671,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
     };
 
     const int items = g.N * cg.rblocks * cg.cblocks;
-    if (p < items && !(ablate & 1)) prefetch(p);
+    if (p < items && !(TNMF_ABL(ablate) & 1)) prefetch(p);
     for (int it = p; it < items; it += cg.P) {
         __syncthreads();   // every wave is done with the previous item's tiles
-        if (!(ablate & 1)) commit(it);
+        if (!(TNMF_ABL(ablate) & 1)) commit(it);
         __syncthreads();
-        if (it + cg.P < items && !(ablate & 1)) prefetch(it + cg.P);   // in flight under the MFMAs below
+        if (it + cg.P < items && !(TNMF_ABL(ablate) & 1)) prefetch(it + cg.P);   // in flight under the MFMAs below
 
         // flattened k loop: 2 rows x TW/4 pixel quads; A offsets are linear, B offsets step by XST at the row change.
         // Fine-grained software pipeline: right after the two MFMAs of column tile t its (V,R) operand pair is reloaded
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_corr_H(Geo g, CorrHGeom cg, 
         float2 bx[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) bx[t] = Xs[bo[t]];
-        for (int st = (ablate & 4) ? nsteps : 1; st < nsteps; ++st) {
+        for (int st = (TNMF_ABL(ablate) & 4) ? nsteps : 1; st < nsteps; ++st) {
             ++sq;
             xo += 4;
             if (sq == nq) {
@@ -761,7 +761,7 @@ constexpr int RC_NE4_MAX = 12;   // 16-byte staging pieces per thread: 128 lines
 
 template <int CB, int NB>
 __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, int xblocks, int cgroups, int ablate,
-                                                                unsigned long long *__restrict__ dbg,
+                                                                unsigned long long *dbg,
                                                                 const float *__restrict__ W,
                                                                 const float *__restrict__ H, float *__restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -772,6 +772,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
     float *Hs = Wl + CB * K4 * 16;             // [MB][RC_RBK][HST]
     float *ring = Hs + MB * RC_RBK * HST;      // [4 waves][CB][16 slots][16 cols]
 
+#ifndef TNMF_DIAG
+    dbg = nullptr;   // product build: every stamp below folds away
+#endif
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int xb = bid % xblocks;
     bid /= xblocks;
@@ -861,7 +864,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
 #pragma unroll
     for (int c = 0; c < CB; ++c) w0[c] = w1[c] = w2[c] = 0.f;
 
-    if (!(ablate & 1)) prefetch(0);
+    if (!(TNMF_ABL(ablate) & 1)) prefetch(0);
     int stage = 0;
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = dbg ? stamp() : 0ull;
     f32x4 acc[RC_RBK][CB];
@@ -920,19 +923,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
                     Wl[i] = ok ? W[((size_t)m * g.C + c) * nA + (g.Ay - 1 - a) * g.Ax + (g.Ax - 1 - b)] : 0.f;
                 }
             }
-            if (!(ablate & 1)) commit(stage);
+            if (!(TNMF_ABL(ablate) & 1)) commit(stage);
             STAMP(2);        // W staging (first stage) + commit
             lds_barrier();
             STAMP(3);        // barrier 2
             if (ch == 0) {
-                if (pending >= 0 && !(ablate & 2)) col2im(pending);
+                if (pending >= 0 && !(TNMF_ABL(ablate) & 2)) col2im(pending);
 #pragma unroll
                 for (int rr = 0; rr < RC_RBK; ++rr)
 #pragma unroll
                     for (int c = 0; c < CB; ++c) acc[rr][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             STAMP(6);        // deferred col2im + R stores of the previous row block
-            if (stage + 1 < nstages && !(ablate & 1)) prefetch(stage + 1);   // in flight under the MFMAs below
+            if (stage + 1 < nstages && !(TNMF_ABL(ablate) & 1)) prefetch(stage + 1);   // in flight under the MFMAs below
             STAMP(4);        // prefetch issue
 
             const float *wl = Wl + kq * 16 + j;
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
                 _Pragma("unroll") for (int c = 0; c < CB; ++c)                                             \
                     acc[rr][c] = mfma16(a_[q][c], b_[q][rr], acc[rr][c]);                                  \
     } while (0)
-                if (!(ablate & 4)) {
+                if (!(TNMF_ABL(ablate) & 4)) {
                     // One scheduling region per two atoms: [load B | multiply A | load A' | multiply B].  The LDS reads
                     // are independent of the MFMAs next to them, and the scheduler is told to alternate them one for
                     // one: a wave issues in order, so reads placed in front of an MFMA block leave the matrix pipe idle
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
             // unrolled by two with two operand register sets (LDS reads of step st+1 fly under the MFMAs of step st)
             const int nb = Axp4 >> 2;
             const int nsteps = MB * nb;
-            int bq = 0, ho = 0, st = (ablate & 4) ? nsteps : 0;
+            int bq = 0, ho = 0, st = (TNMF_ABL(ablate) & 4) ? nsteps : 0;
             float aA[CB], bA[RC_RBK], aB[CB], bB[RC_RBK];
 #define RC_LOAD(a_, b_)                                                                     \
     do {                                                                                    \
@@ -1034,7 +1037,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_mfma_reconstruct(Geo g, int MB, i
         STAMP(5);   // MFMA loop(s)
         pending = rb0;
     }
-    if (pending >= 0 && !(ablate & 2)) col2im(pending);
+    if (pending >= 0 && !(TNMF_ABL(ablate) & 2)) col2im(pending);
     if (dbg && lane == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 4 + wave) * 8 + k] = phase[k];
@@ -1147,23 +1150,44 @@ bool mfma_has_corr_H(const Geo &g, int dtype) {
     return pl.lds <= 80 * 1024 && pl.NT <= 12 && pl.cg.TW <= 72 && g.Hx >= 4 && g.Dx >= 4;
 }
 
+// Opt-in to more than 64 KB of dynamic LDS for every kernel that may ask for it.  The attribute belongs to the
+// (function, device) pair, so it is set per context right after hipSetDevice, not behind a process-wide flag.
+int mfma_prepare_device() {
+#define SET_LDS(K_) TNMF_HIP_TRY(hipFuncSetAttribute((const void *)(K_), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    SET_LDS((k_mfma_reconstruct<1, 0>));
+    SET_LDS((k_mfma_reconstruct<1, 2>));
+    SET_LDS((k_mfma_reconstruct<1, 3>));
+    SET_LDS((k_mfma_reconstruct<1, 4>));
+    SET_LDS((k_mfma_reconstruct<2, 0>));
+    SET_LDS((k_mfma_reconstruct<3, 0>));
+    SET_LDS((k_mfma_reconstruct<4, 0>));
+    SET_LDS((k_mfma_corr_H<1>));
+    SET_LDS((k_mfma_corr_H<2>));
+    SET_LDS((k_mfma_corr_H<3>));
+    SET_LDS((k_mfma_corr_H<4>));
+    SET_LDS((k_mfma_corr_H<5>));
+    SET_LDS((k_mfma_corr_H<6>));
+    SET_LDS((k_mfma_corr_H<7>));
+    SET_LDS((k_mfma_corr_H<8>));
+    SET_LDS((k_mfma_corr_H<9>));
+    SET_LDS((k_mfma_corr_H<10>));
+    SET_LDS((k_mfma_corr_H<11>));
+    SET_LDS((k_mfma_corr_H<12>));
+#undef SET_LDS
+    return TNMF_OK;
+}
+
 int mfma_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, const float *W, const float *H, float *R, hipStream_t s) {
     const ReconPlan pl = plan_reconstruct(g);
     const size_t blocks = (size_t)g.N * pl.cgroups * pl.xblocks;
     if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
     unsigned long long *dbg = nullptr;
-    static const bool want_stamps = getenv("TNMF_HIP_STAMPS") != nullptr;   // diagnostic only
+    static const bool want_stamps = tnmf_diag_env("TNMF_HIP_STAMPS") != nullptr;   // -DTNMF_DIAG builds only
     if (want_stamps) TNMF_HIP_TRY(hipMalloc(&dbg, blocks * 4 * 8 * sizeof(unsigned long long)));
 #define LAUNCH_RC(CB_, NB_)                                                                                        \
     do {                                                                                                           \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set) {                                                                                           \
-            TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_mfma_reconstruct<CB_, NB_>,                           \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
-            attr_set = true;                                                                                       \
-        }                                                                                                          \
         hipLaunchKernelGGL((k_mfma_reconstruct<CB_, NB_>), dim3((unsigned)blocks), dim3(kBlock),                   \
-                           pl.lds + ((ctx->ablate & 4096) ? 40 * 1024 : 0), s, g,                                  \
+                           pl.lds + ((TNMF_ABL(ctx->ablate) & 4096) ? 40 * 1024 : 0), s, g,                                  \
                            pl.MB, pl.xblocks, pl.cgroups, ctx->ablate, dbg, W, H, R);                              \
     } while (0)
 #define LAUNCH_RC_NB(CB_)                 \
@@ -1211,7 +1235,7 @@ int mfma_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R,
         const int SH = CP_TY + g.Ay - 1;
         const size_t lds_p = ((size_t)2 * SH * CW_XSTR + (size_t)g.C * g.Ay * Axp * 32) * sizeof(float);
         const int wpieces = SH * ((CW_TX + Axp - 1 + 3) / 4);
-        if (lds_p <= 52 * 1024 && wpieces <= CP_XE4 * kBlock && g.Dx >= 4 && !(ctx->ablate & 32)) {
+        if (lds_p <= 52 * 1024 && wpieces <= CP_XE4 * kBlock && g.Dx >= 4 && !(TNMF_ABL(ctx->ablate) & 32)) {
             const int tiles_y = cdiv(g.Hy, CP_TY), tiles_x = cdiv(g.Hx, CW_TX), MT = cdiv(g.M, 32);
             const long ntiles = (long)g.N * tiles_y * tiles_x;
             if (ntiles > 0x7fffffffL) return TNMF_E_GEOM;
@@ -1277,12 +1301,6 @@ int mfma_corr_H(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R,
     const dim3 grid(pl.cg.P, pl.MT, pl.JG);
 #define LAUNCH_CH(NT_)                                                                                             \
     case NT_: {                                                                                                    \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set) {                                                                                           \
-            TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_mfma_corr_H<NT_>,                                     \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
-            attr_set = true;                                                                                       \
-        }                                                                                                          \
         hipLaunchKernelGGL((k_mfma_corr_H<NT_>), grid, dim3(kBlock), pl.lds, s, g, pl.cg, ctx->ablate, V, R, H,    \
                            partials);                                                                              \
     } break
