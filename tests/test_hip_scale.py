@@ -191,7 +191,9 @@ def test_foreign_write_to_H_between_fused_calls(path):
     be.fused_update_H(V, W, H, slice(None), sparsity=0., eps=1e-9)       # leaves the row spectra of the new H cached
     on, op = orc.gradient_H(V, Wn, Hn, slice(None), 'c')
     H1 = Hn * on / (op + 1e-9)
-    assert relmax(be.to_ndarray(H), H1) < 4e-5
+    # (the pure FFT path's float32 H update is less exact at small activations -- DESIGN.md 4b; W below is not)
+    assert relmax(be.to_ndarray(H), H1) < (2e-3 if path == 'fft' else 4e-5)
+    H1 = be.to_ndarray(H).astype(np.float64)                            # continue from what the device holds
     H.mul_(0.5)                                                           # a torch-side write the library cannot see
     H[1].add_(0.25)
     H2 = H1 * 0.5

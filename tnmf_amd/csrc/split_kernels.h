@@ -1,0 +1,654 @@
+// split_kernels.h -- the H gradient / fused H update (NumPy.py:93-120 + TransformInvariantNMF.py:232-235) on the gfx950 bf16
+// matrix cores at float32 accuracy.
+//
+// Idea.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the f32-input MFMA.  Every f32 operand is split EXACTLY
+// into three bf16 terms  x = hi + mid + lo  (8 + 8 + 8 significand bits, round-to-nearest at each step, the
+// remainders are exact in f32) and a product  x*y  is formed from the six term products with i + j <= 2
+//       lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi          (smallest first, f32 accumulation in the MFMA),
+// each of which is exact (8 x 8 bits).  What is dropped (mid*lo, lo*mid, lo*lo) is below 2^-23 of the product, i.e. at
+// the level of one f32 rounding; measured against a double reference the scheme is slightly MORE accurate than the
+// f32 MFMA chain.  Six bf16 MFMAs replace eight f32 MFMAs of the same tile: 16/6 = 2.67x the rate.
+//
+// GEMM view: D[atom][pixel] = sum_k W[atom][k] * X[pixel + k], K = (c, a, b): atoms on the MFMA rows, 32 consecutive
+// pixels of one row of the shift plane on the columns = on the lanes.  Two cheap register<->lane bit exchanges in the
+// epilogue (8 v_permlane16_swap + 16 DPP moves per accumulator) then give every lane four consecutive pixels of one atom
+// and eight adjacent lanes 128 contiguous bytes: the read-modify-write of H (4.7 GB per call at config 3, as much time
+// as the MFMAs) is made of fully used cache lines and 16-byte accesses.  (Straight out of either MFMA orientation the
+// same traffic ran at 3.3-3.6 TB/s: 32 atom planes per instruction with pixels in the registers, four times as many
+// instructions with pixels on the lanes.)
+//   X operand (16 k x 32 pixels): lane (i = l & 31, h = l >> 5) holds k = 8h .. 8h+7, i.e. two RUNS of four consecutive
+//   taps b0 .. b0+3 of one atom row.  A run of pixel i is 8 contiguous bytes X[row][i + b0 .. i + b0 + 3] of the bf16
+//   window -- at a 2-byte alignment that depends on i.  LDS reads wider than 4 bytes must be naturally aligned
+//   (cdna_hip_programming.md, Guideline 17), so the window is kept in FOUR copies shifted by 0..3 elements:
+//   copy s holds X[. + s], pixel i reads copy i & 3 at element 4 (i >> 2) + b0: 8-byte aligned.  The copies start 64
+//   bytes apart (mod 256), so the 32 lanes of a half wave -- 8 lanes per copy, 8 bytes each -- cover all 64 banks once.
+//   K order: the runs are enumerated as slots (run r, row pair p), p fastest; lane half h takes atom row 2p + h, so both
+//   halves read at the same compile-time offsets from a lane base that already contains h: no address arithmetic in the
+//   loop.  The two slots of a k block are never adjacent in memory, and the kernel is compiled without hipcc's DS pairing
+//   (target feature load-store-opt): a paired ds_read2_b64 moves 128 bytes per clock where ds_read_b64 moves 256
+//   (MI355X_MICROARCH.md, LDS table), and the LDS pipe is the busiest unit of this kernel after the matrix pipe.
+//   W operand (32 atoms x 16 k): W pre-split on the device into the exact register image [k block][term][lane][8 bf16]
+//   (k_split_prep_W), copied to LDS once per workgroup (one channel) or per stage (several), read with ds_read_b128.
+//
+// Workgroup = 4 waves = a tile of 8 rows x 32 columns of the shift plane x 32 atoms; wave w owns rows 2w, 2w+1, for V
+// and for R: 4 accumulators of 32 x 32.  Persistent: a workgroup walks its tiles; while the MFMAs of a stage run, the
+// next stage's (V, R) window is in flight into registers and so are the H values the epilogue will update.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+
+#include "split.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// device pass only: compile the kernel without hipcc's pairing of DS accesses (see the K-order note above)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TNMF_NO_DS_PAIRING __attribute__((target("no-load-store-opt")))
+#else
+#define TNMF_NO_DS_PAIRING
+#endif
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int SP_TY = 8, SP_TX = 32, SP_RB = 2;
+
+// compile-time geometry of one (atom rows, runs per row) instantiation
+template <int AY, int NR4>
+struct SplitCfg {
+    static constexpr int WSTR = 4 * NR4 + 28;          // window row stride (bf16 elements): 4 (i >> 2) + b0 + 3 <= WSTR - 1
+    static constexpr int Q = WSTR / 4;                 // 4-element pieces per window row
+    static constexpr int SH = SP_TY + AY - 1;          // window rows that hold data
+    static constexpr int SHA = SP_TY + AY;             // + one row of zeros (odd AY: lane half 1 of the last row pair)
+    static constexpr int raw = SHA * WSTR * 2;
+    static constexpr int planeB = ((raw - 64 + 255) / 256) * 256 + 64;   // bytes per (array, copy): == 64 (mod 256)
+    static constexpr int NP = (AY + 1) / 2;            // atom row pairs
+    static constexpr int NSLOT = NP * NR4;             // (row pair, run) slots; a k block holds two
+    static constexpr int KB = (NSLOT + 1) / 2;
+    static constexpr int wimg = KB * 3 * 1024;         // bytes of the W image of one (atom tile, channel)
+    static constexpr int win = 24 * planeB;            // 6 arrays x 4 copies
+    static constexpr int lds = wimg + win;
+    static constexpr int witems = SH * Q;              // staging items (window row, piece) per stage: one per thread
+    static_assert(witems <= kBlock, "one staging item per thread");
+    static_assert(planeB % 8 == 0 && planeB % 256 == 64, "copy bases 64 bytes apart modulo the bank row");
+};
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}), in order
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// -DTNMF_DIAG builds only: cycle stamp (drains the LDS queue: the stamp itself counts on lgkmcnt)
+__device__ __forceinline__ unsigned long long split_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// x = hi + mid + lo exactly, each term a bf16 (bit patterns returned)
+__device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, unsigned &lo) {
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;   // exact: at most 17 significant bits
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;  // exact: at most 9 significant bits, so lo is exact as well
+    const __bf16 l = (__bf16)r2;
+    hi = __builtin_bit_cast(unsigned short, h);
+    mid = __builtin_bit_cast(unsigned short, m);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x2 lo, u32x2 hi) {
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// W[M][C][Ay][Ax] -> register images Wimg[mt][c][kb][term][lane][8 bf16] of the B operand (see the file header):
+// element j of lane (n = l & 31, h = l >> 5) of k block kb is tap (a = 2p + h, b = 4r + (j & 3)) of slot 2 kb + (j >> 2)
+// = (r, p) with p fastest, zero outside the atom / beyond M.
+__global__ void k_split_prep_W(Geo g, int NP, int NSLOT, int KB, const float *__restrict__ W,
+                               u32x4 *__restrict__ Wimg) {
+    const int lane = threadIdx.x;
+    const int kb = blockIdx.x % KB;
+    const int c = (blockIdx.x / KB) % g.C;
+    const int mt = blockIdx.x / (KB * g.C);
+    const int m = mt * 32 + (lane & 31), h = lane >> 5;
+    unsigned t[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int slot = 2 * kb + (j >> 2);
+        const int r = slot / NP, p = slot - r * NP;
+        const int a = 2 * p + h, b = 4 * r + (j & 3);
+        const bool ok = slot < NSLOT && a < g.Ay && b < g.Ax && m < g.M;
+        const float w = ok ? W[(((size_t)m * g.C + c) * g.Ay + a) * g.Ax + b] : 0.f;
+        split3(w, t[0][j], t[1][j], t[2][j]);
+    }
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+        u32x4 v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] = t[term][2 * d] | (t[term][2 * d + 1] << 16);
+        Wimg[(((size_t)(mt * g.C + c) * KB + kb) * 3 + term) * 64 + lane] = v;
+    }
+}
+
+template <bool FUSED, int AY, int NR4>
+__global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(Geo g, int tiles_y, int tiles_x, int ablate,
+                                                            unsigned long long *dbg,
+                                                            const float *__restrict__ V, const float *__restrict__ Rr,
+                                                            const u32x4 *__restrict__ Wimg, float *__restrict__ Hio,
+                                                            float *__restrict__ neg, float *__restrict__ pos,
+                                                            float reg) {
+    using Cfg = SplitCfg<AY, NR4>;
+    constexpr int WSTR = Cfg::WSTR, Q = Cfg::Q, planeB = Cfg::planeB, KB = Cfg::KB, NSLOT = Cfg::NSLOT, NP = Cfg::NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Wl = smem;                  // [KB][3][64 lanes][16 bytes]
+    unsigned char *Xw = smem + Cfg::wimg;      // [6 arrays: V hi, mid, lo, R hi, mid, lo][4 copies][SHA][WSTR] bf16
+
+    const int mt = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+#ifndef TNMF_DIAG
+    dbg = nullptr;   // product build: every stamp below folds away
+#endif
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = dbg ? split_stamp() : 0ull;
+#define SP_STAMP(k_)                                      \
+    do {                                                  \
+        if (dbg) {                                        \
+            __builtin_amdgcn_sched_barrier(0);            \
+            const unsigned long long t_ = split_stamp();  \
+            __builtin_amdgcn_sched_barrier(0);            \
+            phase[k_] += t_ - tprev;                      \
+            tprev = t_;                                   \
+        }                                                 \
+    } while (0)
+
+    // zero the whole window once: the spare row and the slack of every plane stay zero (finite) for good
+    for (int i = threadIdx.x; i < Cfg::win / 16; i += kBlock) reinterpret_cast<u32x4 *>(Xw)[i] = u32x4{0, 0, 0, 0};
+
+    auto stage_W = [&](int c) {
+        const u32x4 *src = Wimg + (size_t)(mt * g.C + c) * (KB * 3 * 64);
+        for (int i = threadIdx.x; i < KB * 3 * 64; i += kBlock) reinterpret_cast<u32x4 *>(Wl)[i] = src[i];
+    };
+    if (g.C == 1) stage_W(0);
+
+    // Work assignment: a workgroup takes whole row blocks (8 rows x the full width of the shift plane of one sample) and
+    // walks their column tiles left to right.  Rows of H are Hx floats long -- not a multiple of the 128-byte cache line --
+    // so every 32-pixel tile shares its first and last line of each row with its neighbours: walked by ONE workgroup the
+    // shared lines are read and written within one L2 (the row block of a plane is one contiguous 8.5 KB region);
+    // dealt to different workgroups they were fetched twice and written back as partial lines from two XCDs (measured
+    // 1.7x the algorithmic H traffic).
+    const int nblocks = g.N * tiles_y;   // row blocks
+    auto stage_coords = [&](int st, int &n, int &u0, int &v0, int &c) {
+        c = st % g.C;
+        const int tl = st / g.C;                                   // tile index within this workgroup's walk
+        const int txi = tl % tiles_x;
+        const int rbk = blockIdx.x + (tl / tiles_x) * gridDim.x;   // row block
+        const int tyi = rbk % tiles_y;
+        n = rbk / tiles_y;
+        u0 = tyi * SP_TY;
+        v0 = txi * SP_TX;
+    };
+
+    // staging item of this thread: window row wr, piece wq (elements 4 wq .. 4 wq + 3 of all four copies, which need
+    // window elements 4 wq .. 4 wq + 6)
+    const int item = threadIdx.x < Cfg::witems ? threadIdx.x : 0;
+    const int wr = item / Q, wq = item - wr * Q;
+    // The window of the next stage is prefetched with FOUR 16-byte loads per thread (elements 0..3 and 4..7 of V and of
+    // R) on clamped, always legal start columns; they are issued one at a time INSIDE the MFMA loop (mem_slot below).
+    // Issued as a burst in front of the loop, the memory instructions of a stage (8 waves of a CU at once) fill the
+    // address FIFO of the texture unit until their misses come back -- the L1 keeps ~128 lines in flight -- and every
+    // wave sits at its next load instead of starting its MFMAs (measured: a third of the kernel).
+    f32x4 pw[4];            // V[0..3], V[4..7], R[0..3], R[4..7] as loaded
+    const float *prow[2];   // row of V / R the loads go to
+    int pxs[2];             // clamped start columns of the two pieces
+    auto prefetch_setup = [&](int st) {
+        int n, u0, v0, c;
+        stage_coords(st, n, u0, v0, c);
+        const int y = u0 + wr - (g.Ay - 1);
+        const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1);
+        prow[0] = V + (((size_t)n * g.C + c) * g.Dy + yc) * g.Dx;
+        prow[1] = Rr + (((size_t)n * g.C + c) * g.Dy + yc) * g.Dx;
+        const int x0 = v0 + 4 * wq - (g.Ax - 1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int x = x0 + 4 * k;
+            pxs[k] = x < 0 ? 0 : (x < g.Dx - 4 ? x : g.Dx - 4);
+        }
+    };
+    auto prefetch_issue = [&](int k) {   // k = 0..3
+        pw[k] = *reinterpret_cast<const f32x4_u *>(prow[k >> 1] + pxs[k & 1]);
+    };
+    // convert(): prefetched f32 window values -> the six bf16 term arrays, packed, still in registers.  It runs right
+    // after the MFMA loop (the loads have long landed) and BEFORE the epilogue's stores: hipcc cannot count conditional
+    // stores, so a wait for the prefetch that came after them would be a full drain of the H stores (2-3 us each stage).
+    // commit(): registers -> the four shifted LDS copies; touches no global memory, so it waits for nothing.
+    unsigned tp[6][4];   // [V hi, V mid, V lo, R hi, R mid, R lo][element pair (0,1) (2,3) (4,5) (6,-)]
+    unsigned tq[6][3];   // the odd pairs (1,2) (3,4) (5,6) for the copies shifted by 1 and 3
+    auto convert = [&](int st) {
+        int n, u0, v0, c;
+        stage_coords(st, n, u0, v0, c);
+        const int y = u0 + wr - (g.Ay - 1);
+        const bool yok = y >= 0 && y < g.Dy;
+        const int x0 = v0 + 4 * wq - (g.Ax - 1);
+        float fv[7], fr[7];
+        // wave-uniform: every 4-column piece of this tile's window lies inside the image row (the second piece of the
+        // last item ends at window column WSTR + 3) -> no start column was clamped, the pieces sit where they belong
+        const bool xin = v0 - (g.Ax - 1) >= 0 && v0 - (g.Ax - 1) + WSTR + 4 <= g.Dx;
+        if (xin) {
+#pragma unroll
+            for (int e = 0; e < 7; ++e) {
+                fv[e] = yok ? pw[e >> 2][e & 3] : 0.f;
+                fr[e] = yok ? pw[2 + (e >> 2)][e & 3] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 7; ++e) {
+                const int x = x0 + e;
+                const bool ok = yok && x >= 0 && x < g.Dx;
+                const int xs = x0 + 4 * (e >> 2);
+                const int d = x - (xs < 0 ? 0 : (xs < g.Dx - 4 ? xs : g.Dx - 4));   // 0..3 whenever x is inside the row
+                const f32x4 a = pw[e >> 2], b = pw[2 + (e >> 2)];
+                const float va = d == 0 ? a[0] : d == 1 ? a[1] : d == 2 ? a[2] : a[3];
+                const float vb = d == 0 ? b[0] : d == 1 ? b[1] : d == 2 ? b[2] : b[3];
+                fv[e] = ok ? va : 0.f;
+                fr[e] = ok ? vb : 0.f;
+            }
+        }
+        unsigned t[6][7];
+#pragma unroll
+        for (int e = 0; e < 7; ++e) {
+            split3(fv[e], t[0][e], t[1][e], t[2][e]);
+            split3(fr[e], t[3][e], t[4][e], t[5][e]);
+        }
+#pragma unroll
+        for (int ar = 0; ar < 6; ++ar) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                tp[ar][k] = t[ar][2 * k] | (t[ar][2 * k + 1] << 16);
+                tq[ar][k] = t[ar][2 * k + 1] | (t[ar][2 * k + 2] << 16);
+            }
+            tp[ar][3] = t[ar][6];
+        }
+    };
+    auto commit = [&]() {
+        if (threadIdx.x < Cfg::witems) {
+            unsigned char *dst = Xw + (wr * WSTR + 4 * wq) * 2;
+#pragma unroll
+            for (int ar = 0; ar < 6; ++ar) {
+                // copy s holds window elements s .. s+3 of this piece
+                *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 0) * planeB) = u32x2{tp[ar][0], tp[ar][1]};
+                *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 1) * planeB) = u32x2{tq[ar][0], tq[ar][1]};
+                *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 2) * planeB) = u32x2{tp[ar][1], tp[ar][2]};
+                *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 3) * planeB) = u32x2{tq[ar][1], tq[ar][2]};
+            }
+        }
+    };
+
+    const int my_tiles = (blockIdx.x < nblocks ? (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0) * tiles_x;
+    const int my_stages = my_tiles * g.C;
+    if (my_stages > 0) {
+        prefetch_setup(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) prefetch_issue(k);
+        convert(0);
+    }
+
+    // lane base of the A reads (bytes into Xw): copy (j & 3), window row 2 wave + h, element 4 (j >> 2)
+    // Column j of the MFMA tile is pixel pj = 4 (j & 7) + (j >> 3) of the 32-pixel tile row, not pixel j: with this
+    // permutation the epilogue's two register<->lane bit exchanges (see there) leave every lane with FOUR CONSECUTIVE
+    // pixels of one atom and eight adjacent lanes with 128 contiguous bytes.  Copy pj & 3 = j >> 3, element 4 (pj >> 2):
+    // the 32 lanes of a half wave still cover the 64 banks exactly once.
+    const unsigned char *abase = Xw + (j >> 3) * planeB + ((2 * wave + h) * WSTR + 4 * (j & 7)) * 2;
+    const unsigned char *bbase = Wl + lane * 16;
+
+    f32x16 acc[SP_RB][2];   // [row of the wave][V | R]
+    float hv[SP_RB][16];
+    // One stage = (tile, channel).  LAST (compile time) marks the last channel of a tile, the stage that loads the H
+    // values and runs the epilogue: as straight-line code, so that hipcc sees every H load consumed on every path (with a
+    // run-time `c == C-1` around both, the loads count as pending at the loop back edge and the next H loads into the same
+    // registers wait for the whole window prefetch issued in between).
+    auto stage = [&](auto lastc, int st) {
+        constexpr bool LAST = decltype(lastc)::value;
+        int n, u0, v0, c;
+        stage_coords(st, n, u0, v0, c);
+        if (c == 0) {
+#pragma unroll
+            for (int rb = 0; rb < SP_RB; ++rb) acc[rb][0] = acc[rb][1] = zero16();
+        }
+        SP_STAMP(0);     // stores of the previous epilogue issued, loop overhead
+        lds_barrier();   // every wave is done with the previous window and W image (first time: the zero fill)
+        SP_STAMP(1);     // barrier 1
+        if (g.C > 1) stage_W(c);
+        if (!(TNMF_ABL(ablate) & 1)) commit();
+        lds_barrier();
+        SP_STAMP(2);     // commit + barrier 2
+        const bool more = st + 1 < my_stages && !(TNMF_ABL(ablate) & 1);
+        if (more) prefetch_setup(st + 1);
+
+        // Accumulator layout out of the 32x32 MFMA (atoms on the rows): lane (column j, h), register r <-> atom
+        // (r & 3) + 8 (r >> 2) + 4h, pixel pj.  The epilogue exchanges register bit 1 with lane bit 4 (v_permlane16_swap)
+        // and register bit 0 with lane bit 3 (DPP row_ror:8 under bank masks); AFTERWARDS register 4q + e of lane (j, h) is
+        // pixel 4 (j & 7) + e of atom ((j >> 3) & 3) + 4h + 8q: 16 contiguous bytes per lane and register group, eight
+        // adjacent lanes = 128 contiguous bytes of one atom plane, eight atoms per instruction -- the read-modify-write of H
+        // goes through fully used cache lines with the fewest possible instructions (8 loads + 8 stores per wave and stage).
+        // H of sample n is addressed through a buffer descriptor (base = first plane of the sample, size = M planes) with
+        // 32-bit byte offsets; its range check drops the atoms beyond M of a partial atom tile.
+        const unsigned plane4 = (unsigned)g.Hy * g.Hx * 4;   // bytes of one atom plane
+        const int p0 = v0 + 4 * (j & 7);                     // first of this lane's four pixels
+        const int p0c = p0 < g.Hx - 4 ? p0 : g.Hx - 4;
+        const bool interior = v0 + SP_TX <= g.Hx;            // wave-uniform: whole tile inside the row
+        const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(Hio + (size_t)n * g.M * g.Hy * g.Hx), 0, (int)(g.M * plane4), 0x00020000);
+        unsigned hoff[SP_RB];   // byte offset of (atom of register group 0, row, first pixel), start column clamped
+#pragma unroll
+        for (int rb = 0; rb < SP_RB; ++rb) {
+            const int u = u0 + wave * SP_RB + rb;
+            hoff[rb] = (unsigned)(mt * 32 + ((j >> 3) & 3) + 4 * h) * plane4 +
+                       ((unsigned)(u < g.Hy ? u : g.Hy - 1) * g.Hx + p0c) * 4;
+        }
+        // H values of this lane's outputs, consumed only in the epilogue: UNCONDITIONAL 16-byte loads on clamped, always
+        // legal addresses, issued one per MFMA group from inside the loop (mem_slot)
+        const bool hload = FUSED && LAST && !(TNMF_ABL(ablate) & 128);
+        auto h_issue = [&](int k) {   // k = 0..7 = (row of the wave, register group)
+            const int rb = k >> 2, q = k & 3;
+            const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (int)(hoff[rb] + 8u * q * plane4), 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned w = t4[e];
+                hv[rb][4 * q + e] = __builtin_bit_cast(float, w);
+            }
+        };
+        // memory slot k of the stage: 0..7 the H loads (last channel of a fused update), 8..11 the window prefetch
+        auto mem_slot = [&](int k) {
+            if (k < 8) {
+                if (hload) h_issue(k);
+            } else if (more) {
+                prefetch_issue(k - 8);
+            }
+        };
+        if (TNMF_ABL(ablate) & 4) {   // (diagnostic builds: no MFMA loop to hide them in)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) mem_slot(k);
+        }
+
+        SP_STAMP(3);     // issue of the window prefetch and the H loads
+        // ---- MFMA loop: groups g = (k block, row, V | R) of six MFMAs; the operands of group g+1 (six 8-byte reads)
+        // and, once per k block, the three W terms of the next k block are fetched under the MFMAs of group g.
+        if (!(TNMF_ABL(ablate) & 4)) {
+            constexpr int G = KB * 4;
+            u32x2 a[2][3][2];   // [buffer][term][run of the k block]
+            u32x4 b[2][3];      // [buffer][term]
+            auto load_a = [&](int buf, int gi) {
+                const int kb = gi >> 2, rb = (gi >> 1) & 1, x = gi & 1;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    int slot = 2 * kb + e;
+                    if (slot >= NSLOT) slot = NSLOT - 1;   // odd slot count: W is zero there, any legal address serves
+                    const int r = slot / NP, p = slot - r * NP;   // consecutive slots: consecutive row pairs, same run
+                    const int off = ((rb + 2 * p) * WSTR + 4 * r) * 2;
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+                        a[buf][term][e] = *reinterpret_cast<const u32x2 *>(abase + (3 * x + term) * 4 * planeB + off);
+                }
+            };
+            auto load_b = [&](int buf, int kb) {
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+                    b[buf][term] = *reinterpret_cast<const u32x4 *>(bbase + (kb * 3 + term) * 1024);
+            };
+            load_b(0, 0);
+            load_a(0, 0);
+            static_for<G>([&](auto gic) {
+                constexpr int gi = decltype(gic)::value;
+                constexpr int kb = gi >> 2, rb = (gi >> 1) & 1, x = gi & 1;
+                constexpr int ab = gi & 1, bb = kb & 1;
+                constexpr bool nextb = (gi & 3) == 0 && kb + 1 < KB;
+                if constexpr (gi + 1 < G) load_a(ab ^ 1, gi + 1);
+                if constexpr (nextb) load_b(bb ^ 1, kb + 1);
+                // one memory instruction of the stage per group, over the first part of the loop (H loads first: the
+                // epilogue right behind the loop needs them; then the next window, needed one barrier later)
+                constexpr int MSTRIDE = G >= 24 ? G / 24 : 1;
+                if constexpr (gi % MSTRIDE == 0 && gi / MSTRIDE < 12) mem_slot(gi / MSTRIDE);
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 ahi = as_bf16x8(a[ab][0][0], a[ab][0][1]);
+                const bf16x8 amid = as_bf16x8(a[ab][1][0], a[ab][1][1]);
+                const bf16x8 alo = as_bf16x8(a[ab][2][0], a[ab][2][1]);
+                const bf16x8 bhi = __builtin_bit_cast(bf16x8, b[bb][0]);
+                const bf16x8 bmid = __builtin_bit_cast(bf16x8, b[bb][1]);
+                const bf16x8 blo = __builtin_bit_cast(bf16x8, b[bb][2]);
+                f32x16 d = acc[rb][x];       // D[atom][pixel] += W[atom][k] * X[k][pixel]
+                d = mfma_bf16(bhi, alo, d);    // smallest terms first
+                d = mfma_bf16(blo, ahi, d);
+                d = mfma_bf16(bmid, amid, d);
+                d = mfma_bf16(bhi, amid, d);
+                d = mfma_bf16(bmid, ahi, d);
+                d = mfma_bf16(bhi, ahi, d);
+                acc[rb][x] = d;
+                // Order pinned by hand: the reads of the next group go out in one burst in the shadow of the previous
+                // group's last MFMA (an MFMA holds the wave's issue port for 8 of its 32 cycles), then the six MFMAs run
+                // back to back.  (sched_group_barrier pipelines over this fully unrolled loop cost hipcc minutes per
+                // instantiation; two plain scheduling fences per group give the same instruction stream.)
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+
+        SP_STAMP(4);     // MFMA loop
+        if (more) convert(st + 1);   // before the stores below (see convert)
+        SP_STAMP(5);     // convert (the prefetched window has landed under the loop)
+
+        if (LAST && !(TNMF_ABL(ablate) & 8)) {
+            // ---- register <-> lane bit exchanges (see the layout note at the H prefetch)
+            // (a) register bit 1 <-> lane bit 4: v_permlane16_swap x, y exchanges the odd 16-lane rows of x with the even
+            //     rows of y; x = register r (bit 1 clear), y = register r + 2.
+            // (b) register bit 0 <-> lane bit 3: lanes 8..15 of every row take the partner register from the lane 8 below,
+            //     lanes 0..7 from the lane 8 above: two DPP moves (row_ror:8) under bank masks, no select.
+#pragma unroll
+            for (int rb = 0; rb < SP_RB; ++rb)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    unsigned w[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float f = acc[rb][x][r];
+                        w[r] = __builtin_bit_cast(unsigned, f);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (!(r & 2)) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(w[r], w[r + 2], false, false);
+                            w[r] = sw[0];
+                            w[r + 2] = sw[1];
+                        }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (!(r & 1)) {
+                            const unsigned a0 = w[r], a1 = w[r + 1];
+                            w[r] = __builtin_amdgcn_update_dpp(a0, a1, 0x128, 0xF, 0xC, false);       // lanes 8..15: a1 of lane-8
+                            w[r + 1] = __builtin_amdgcn_update_dpp(a1, a0, 0x128, 0xF, 0x3, false);   // lanes 0..7: a0 of lane+8
+                        }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned wr_ = w[r];
+                        acc[rb][x][r] = __builtin_bit_cast(float, wr_);
+                    }
+                }
+            SP_STAMP(6);   // register <-> lane exchanges
+            if (FUSED && !interior) {
+                // lanes whose four pixels straddle the end of the row loaded from Hx-4: move element e + d to e (d = 1..3);
+                // groups entirely beyond the row keep values nobody uses
+                const int d = p0 - p0c;
+#pragma unroll
+                for (int rb = 0; rb < SP_RB; ++rb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float t0 = hv[rb][4 * q], t1 = hv[rb][4 * q + 1], t2 = hv[rb][4 * q + 2], t3 = hv[rb][4 * q + 3];
+                        hv[rb][4 * q] = d == 0 ? t0 : d == 1 ? t1 : d == 2 ? t2 : t3;
+                        hv[rb][4 * q + 1] = d == 0 ? t1 : d == 1 ? t2 : t3;
+                        hv[rb][4 * q + 2] = d == 0 ? t2 : t3;
+                    }
+            }
+            // The arithmetic consumes every prefetched H value UNCONDITIONALLY (only the stores are predicated): a load
+            // whose result is used on some paths only stays "pending" for hipcc's wait-count pass at the loop back edge,
+            // and the next stage's H loads into the same registers would then wait for the window prefetch in between.
+            const size_t sample = (size_t)n * g.M * g.Hy * g.Hx;
+            const __amdgpu_buffer_rsrc_t nrsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(neg + (FUSED ? 0 : sample)), 0, (int)(g.M * plane4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t prsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(pos + (FUSED ? 0 : sample)), 0, (int)(g.M * plane4), 0x00020000);
+#pragma unroll
+            for (int rb = 0; rb < SP_RB; ++rb) {
+                const int u = u0 + wave * SP_RB + rb;
+                const bool urow = u < g.Hy;
+                // un-clamped offset of the first pixel (the stores of a border tile go element by element)
+                const unsigned soff = hoff[rb] + (unsigned)(p0 - p0c) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u32x4 o4, n4, q4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float nv = acc[rb][0][4 * q + e], pv_ = acc[rb][1][4 * q + e];
+                        // H * neg / (pos + reg), hardware reciprocal (1 ulp): inside the f32 parity budget
+                        const float ov = FUSED ? __fdividef(hv[rb][4 * q + e] * nv, pv_ + reg) : 0.f;
+                        o4[e] = __builtin_bit_cast(unsigned, ov);
+                        n4[e] = __builtin_bit_cast(unsigned, nv);
+                        q4[e] = __builtin_bit_cast(unsigned, pv_);
+                    }
+                    const int off = (int)(soff + 8u * q * plane4);
+                    if (interior) {
+                        if (urow) {
+                            if (FUSED) {
+                                __builtin_amdgcn_raw_buffer_store_b128(o4, hrsrc, off, 0, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b128(n4, nrsrc, off, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(q4, prsrc, off, 0, 0);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (urow && p0 + e < g.Hx) {
+                                const unsigned ow = o4[e], nw = n4[e], qw = q4[e];
+                                if (FUSED) {
+                                    __builtin_amdgcn_raw_buffer_store_b32(ow, hrsrc, off + 4 * e, 0, 0);
+                                } else {
+                                    __builtin_amdgcn_raw_buffer_store_b32(nw, nrsrc, off + 4 * e, 0, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b32(qw, prsrc, off + 4 * e, 0, 0);
+                                }
+                            }
+                    }
+                }
+            }
+        }
+    };
+    int st = 0;
+    for (int t = 0; t < my_tiles; ++t) {
+        for (int c = 0; c + 1 < g.C; ++c, ++st) stage(std::false_type{}, st);
+        stage(std::true_type{}, st);
+        ++st;
+    }
+    if (dbg) {
+        SP_STAMP(7);   // wait for H, update arithmetic, store issue of the last stage (the others land in phase 0)
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + k] = phase[k];
+        }
+    }
+#undef SP_STAMP
+}
+
+template <int AY, int NR4>
+int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *W, float *H_inout,
+           float *neg, float *pos, bool fused, float reg, hipStream_t s) {
+    using Cfg = SplitCfg<AY, NR4>;
+    const int MT = cdiv(g.M, 32);
+    const size_t wbytes = (size_t)MT * g.C * Cfg::wimg;
+    if (wbytes > ctx->wimg_bytes) {
+        if (ctx->wimg) {
+            TNMF_HIP_TRY(hipDeviceSynchronize());
+            TNMF_HIP_TRY(hipFree(ctx->wimg));
+            ctx->wimg = nullptr;
+            ctx->wimg_bytes = 0;
+        }
+        if (hipMalloc(&ctx->wimg, wbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return TNMF_E_WORKSPACE;
+        }
+        ctx->wimg_bytes = wbytes;
+    }
+    hipLaunchKernelGGL(k_split_prep_W, dim3(MT * g.C * Cfg::KB), dim3(64), 0, s, g, Cfg::NP, Cfg::NSLOT, Cfg::KB, W,
+                       (u32x4 *)ctx->wimg);
+    const int tiles_y = cdiv(g.Hy, SP_TY), tiles_x = cdiv(g.Hx, SP_TX);
+    const long ntiles = (long)g.N * tiles_y * tiles_x;
+    if (ntiles > 0x7fffffffL) return TNMF_E_GEOM;
+    const int per_cu = Cfg::lds <= 80 * 1024 ? 2 : 1;
+    long P = ((long)per_cu * ctx->num_cu) / MT;
+    if (P < 1) P = 1;
+    if (P > (long)g.N * tiles_y) P = (long)g.N * tiles_y;   // a workgroup walks whole row blocks
+    const dim3 grid((unsigned)P, MT);
+    unsigned long long *dbg = nullptr;
+    const size_t nw = (size_t)P * MT * 4;
+    static const bool want_stamps = tnmf_diag_env("TNMF_HIP_STAMPS") != nullptr;   // -DTNMF_DIAG builds only
+    if (want_stamps) TNMF_HIP_TRY(hipMalloc(&dbg, nw * 8 * sizeof(unsigned long long)));
+    if (fused)
+        hipLaunchKernelGGL((k_split_corr_W<true, AY, NR4>), grid, dim3(kBlock), Cfg::lds, s, g, tiles_y, tiles_x,
+                           ctx->ablate, dbg, V, R, (const u32x4 *)ctx->wimg, H_inout, (float *)nullptr, (float *)nullptr,
+                           reg);
+    else
+        hipLaunchKernelGGL((k_split_corr_W<false, AY, NR4>), grid, dim3(kBlock), Cfg::lds, s, g, tiles_y, tiles_x,
+                           ctx->ablate, dbg, V, R, (const u32x4 *)ctx->wimg, (float *)nullptr, neg, pos, 0.f);
+    TNMF_LAUNCH_CHECK();
+    if (dbg) {
+        TNMF_HIP_TRY(hipStreamSynchronize(s));
+        unsigned long long *hbuf = (unsigned long long *)malloc(nw * 8 * sizeof(unsigned long long));
+        TNMF_HIP_TRY(hipMemcpy(hbuf, dbg, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double sum[8] = {0};
+        for (size_t w = 0; w < nw; ++w)
+            for (int k = 0; k < 8; ++k) sum[k] += (double)hbuf[w * 8 + k];
+        static const char *names[8] = {"epilogue(H wait, update, stores)", "barrier1", "commit+barrier2", "load issue",
+                                       "mfma", "prefetch wait+convert", "exchange", "tail"};
+        double tot = 0;
+        for (int k = 0; k < 8; ++k) tot += sum[k];
+        fprintf(stderr, "[stamps split] cycles per wave:");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f (%.1f%%)", names[k], sum[k] / nw, 100.0 * sum[k] / tot);
+        fprintf(stderr, " total %.0f\n", tot / nw);
+        free(hbuf);
+        TNMF_HIP_TRY(hipFree(dbg));
+    }
+    return TNMF_OK;
+}
+
+template <int AY, int NR4>
+int prepare_one() {
+    TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_split_corr_W<true, AY, NR4>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_split_corr_W<false, AY, NR4>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return TNMF_OK;
+}
+
+}  // namespace

@@ -1,11 +1,15 @@
-import json, sys
-d = json.load(open(sys.argv[1]))
-print("it/s %.2f  ms/step %.2f  path %s  frac_peak %.3f" % (d["value"], d["ms_per_step"], d["config"]["kernel_path"], d["iteration"]["frac_f32_peak"]))
+"""Prints the headline numbers of one bench.py JSON line (file given as argv[1])."""
+import json
+import sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("it/s %.2f  ms/step %.3f  path %s" % (d["value"], d["ms_per_step"], d["config"]["kernel_path"]))
 for k, v in d["kernels"].items():
-    r = d.get("roofline_by_kernel", {}).get(k)
-    extra = ("%-4s %s %.3g %s (frac %.2f)" % (v.get("family"), r["bound"], r["achieved"], r["unit"], r["frac"])) if r else ""
-    print("  %-12s avg %.3f ms  %s" % (k, v["avg_ms"], extra))
-for lab in ("direct_variant", "fft_variant"):
-    if lab in d and "value" in d[lab]:
-        v = d[lab]
-        print("  %-15s %.2f it/s  %.2f ms/step  x%.2f of main  dW %.1e" % (lab, v["value"], v["ms_per_step"], v["speed_relative_to_main"], v["W_max_rel_diff_vs_main"]))
+    print("  %-12s %-6s avg %.3f ms x %d" % (k, v.get("family"), v["avg_ms"], v["launches"]))
+for k in ("exact_f32_variant", "direct_variant", "fft_variant"):
+    if k in d and "value" in d[k]:
+        print("  %s: %.2f it/s  %s" % (k, d[k]["value"], {a: round(b, 3) for a, b in d[k]["kernels_ms"].items()}))
+if "parity" in d:
+    p = d["parity"]
+    print("  parity (%d samples): dW %.2e dH %.2e dE %.2e" % (p["samples"], p["W_rel_diff_vs_oracle"], p["H_rel_diff_vs_oracle"], p["energy_gap_vs_oracle"]))
+r = d["roofline"]
+print("  roofline: %s %s %.1f / %.0f %s = %.3f" % (r["kernel"], r["family"], r["achieved"], r["peak"], r["unit"], r["frac"]))

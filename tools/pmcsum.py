@@ -1,22 +1,17 @@
-"""Summarise rocprofv3 --pmc counter_collection.csv files: per kernel, per-dispatch averages."""
-import csv, collections, glob, re, sys
-def short(n):
-    m = re.search(r'(k_\w+)(<[^>]*>)?', n)
-    return (m.group(1) + (m.group(2) or '')) if m else n[:30]
-for d in sys.argv[1:]:
-    for f in glob.glob(d + '/*/*_counter_collection.csv'):
-        rows = list(csv.DictReader(open(f)))
-        agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
-        dur = collections.defaultdict(float); info = {}
-        for r in rows:
-            k = short(r['Kernel_Name'])
-            if not k.startswith('k_'): continue
-            agg[k][r['Counter_Name']] += float(r['Counter_Value'])
-            if r['Dispatch_Id'] not in disp[k]:
-                disp[k].add(r['Dispatch_Id']); dur[k] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
-                info[k] = 'grid %s wg %s lds %s scratch %s vgpr %s agpr %s sgpr %s' % (r['Grid_Size'], r['Workgroup_Size'], r['LDS_Block_Size'], r['Scratch_Size'], r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'])
-        for k, v in agg.items():
-            n = len(disp[k])
-            if dur[k] / n < 2e5: continue
-            print('%s  %s: %d dispatches, avg %.3f ms  [%s]' % (d, k, n, dur[k] / n / 1e6, info[k]))
-            for c, val in sorted(v.items()): print('   %-28s %.4g' % (c, val / n))
+"""Averages per kernel (name substring argv[2], default all) of the rocprofv3 --pmc CSVs under a directory (argv[1])."""
+import collections
+import csv
+import glob
+import os
+import sys
+root = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else ''
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if pat in r['Kernel_Name']:
+            agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, cs in agg.items():
+    print(k)
+    for c, v in sorted(cs.items()):
+        print(f'   {c:45s} n={len(v):3d}  avg={sum(v) / len(v):.4g}')
