@@ -107,9 +107,9 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
     l->SWf = take(nSW);
     l->TW = take((size_t)2 * g.M * g.C * g.Ay * kxp * c);
     l->Wt = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
-    // partial W-gradient spectra: [groups][M*C][Ly][KXP] for the column-transform kernel, [<= 32 groups][M*C][Ay][KXP]
+    // partial W-gradient spectra: [groups][M*C][Ly][KXP] for the column-transform kernel, [<= 64 groups][M*C][Ay][KXP]
     // for the mixed kernel
-    const size_t nG = std::max(nSW * l->ngroups, (size_t)32 * g.M * g.C * g.Ay * kxp * c);
+    const size_t nG = std::max(nSW * l->ngroups, (size_t)64 * g.M * g.C * g.Ay * kxp * c);
     l->Gn = take(nG);
     l->Gp = take(nG);
     l->Gs = take(nSW * 2);
@@ -529,9 +529,11 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
     if (mixed) {
         // transform along x only; the Ay lags along y are accumulated directly (fft_mixed.hip)
         CHECK(forward_rows(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.RT), s));
-        int ng_want = 32;
+        // sample groups = partial sums: the two-atom kernel (atoms up to 12 rows) has half as many atom blocks, so it
+        // takes twice the groups to keep ~2.5 waves per SIMD in the grid
+        int ng_want = g.Ay <= 12 ? 64 : 32;
         if (const char *e = tnmf_diag_env("TNMF_MIX_GROUPS")) ng_want = atoi(e);   // diagnostic builds only
-        ng_want = ng_want < 1 ? 1 : (ng_want > 32 ? 32 : ng_want);                 // Gn/Gp hold 32 groups
+        ng_want = ng_want < 1 ? 1 : (ng_want > 64 ? 64 : ng_want);                 // Gn/Gp hold 64 groups
         int ng = g.N < ng_want ? g.N : ng_want;
         const int nper = cdiv(g.N, ng);
         ng = cdiv(g.N, nper);

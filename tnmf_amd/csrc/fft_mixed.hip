@@ -214,10 +214,103 @@ __global__ __launch_bounds__(kMixCols *GROUPS, 2) void k_mix_grad_W(const cplx<T
     }
 }
 
+// Two atoms per thread: the V^/R^ row entries -- the operand every atom block re-reads -- are loaded once for both, and
+// the address arithmetic and loop overhead of a row are shared.  Rows are taken one at a time through register rings
+// that are indexed statically (the row loop is unrolled over one ring period): RS >= AY + 4 slots per atom for the row
+// spectra of H (row y needs T[y .. y+AY-1]; the rows behind them are in flight), VS = 8 slots for V^ and R^ (7 rows in
+// flight); RS is a multiple of VS so that one period of RS rows serves both rings.
+template <typename T, int AY, int GROUPS>
+__global__ __launch_bounds__(kMixCols *GROUPS, 2) void k_mix_grad_W2(const cplx<T> *Tsp, const cplx<T> *VT,
+                                                                  const cplx<T> *RT, cplx<T> *Gn, cplx<T> *Gp, int N,
+                                                                  int M, int Hy, int Dy, int KX, int KXP, int nper) {
+    constexpr int MA = 2, VS = 8, RS = (AY + 4 + VS - 1) / VS * VS, P = VS - 1;
+    const int col = threadIdx.x & (kMixCols - 1), sub = threadIdx.x / kMixCols;
+    const int kx = blockIdx.y * kMixCols + col, kxc = min(kx, KX - 1);
+    const int m0 = blockIdx.x * MA, grp = blockIdx.z * GROUPS + sub;
+    const int m1 = min(m0 + 1, M - 1);   // odd M: the second atom of the last block repeats the first (not stored)
+    cplx<T> an[MA][AY], ap[MA][AY];
+#pragma unroll
+    for (int q = 0; q < MA; ++q)
+#pragma unroll
+        for (int a = 0; a < AY; ++a) {
+            an[q][a] = {0, 0};
+            ap[q][a] = {0, 0};
+        }
+    const int nbeg = grp * nper, nend = min(N, nbeg + nper);
+    const long tplane = (long)Hy * KXP, vplane = (long)Dy * KXP;
+#pragma unroll 1
+    for (int n = nbeg; n < nend; ++n) {
+        const cplx<T> *tp0 = Tsp + ((long)n * M + m0) * tplane, *tp1 = Tsp + ((long)n * M + m1) * tplane;
+        const cplx<T> *vp = VT + (long)n * vplane, *rp = RT + (long)n * vplane;
+        cplx<T> t[MA][RS], v[VS], r[VS];
+        // rows 0 .. RS-2 of the H spectra, rows 0 .. P-1 of V^/R^ (row indices clamped: always legal addresses)
+#pragma unroll
+        for (int i = 0; i < RS - 1; ++i) {
+            const unsigned o = (unsigned)(min(i, Hy - 1) * KXP + kxc);
+            t[0][i] = tp0[o];
+            t[1][i] = tp1[o];
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const unsigned o = (unsigned)(min(i, Dy - 1) * KXP + kxc);
+            v[i] = vp[o];
+            r[i] = rp[o];
+        }
+#pragma unroll 1
+        for (int yb = 0; yb < Dy; yb += RS) {
+            // one period of both rings: every ring index below is a compile-time constant
+#pragma unroll
+            for (int i = 0; i < RS; ++i) {
+                const int y = yb + i;
+                if (y >= Dy) break;   // wave-uniform
+                // fetch: H row y + RS - 1 into the slot row y - 1 left, V^/R^ row y + P into the slot row y - 1 left
+                {
+                    const unsigned o = (unsigned)(min(y + RS - 1, Hy - 1) * KXP + kxc);
+                    t[0][(i + RS - 1) % RS] = tp0[o];
+                    t[1][(i + RS - 1) % RS] = tp1[o];
+                    const unsigned ov = (unsigned)(min(y + P, Dy - 1) * KXP + kxc);
+                    v[(i + P) % VS] = vp[ov];
+                    r[(i + P) % VS] = rp[ov];
+                }
+                const cplx<T> vy = v[i % VS], ry = r[i % VS];
+#pragma unroll
+                for (int a = 0; a < AY; ++a) {
+                    cfmac(an[0][a], t[0][(i + a) % RS], vy);
+                    cfmac(ap[0][a], t[0][(i + a) % RS], ry);
+                    cfmac(an[1][a], t[1][(i + a) % RS], vy);
+                    cfmac(ap[1][a], t[1][(i + a) % RS], ry);
+                }
+            }
+        }
+    }
+    if (kx >= KX) return;
+    const long gplane = (long)AY * KXP, gsize = (long)M * gplane;
+#pragma unroll
+    for (int q = 0; q < MA; ++q) {
+        if (m0 + q >= M) break;
+#pragma unroll
+        for (int a = 0; a < AY; ++a) {
+            const long o = (long)grp * gsize + (long)(m0 + q) * gplane + (long)a * KXP + kx;
+            Gn[o] = an[q][a];
+            Gp[o] = ap[q][a];
+        }
+    }
+}
+
 template <typename T, int AY>
 int launch_mix_grad_W(const void *Tsp, const void *VT, const void *RT, void *Gn, void *Gp, const Geo &g, int KX,
                       int KXP, int ngroups, int nper, hipStream_t s) {
     constexpr int GROUPS = 4;
+    if constexpr (AY <= 12) {   // (taller atoms: the two-atom variant no longer fits the register file)
+        if (g.C == 1) {
+            const dim3 grid((unsigned)cdiv(g.M, 2), (unsigned)cdiv(KX, kMixCols), (unsigned)cdiv(ngroups, GROUPS));
+            hipLaunchKernelGGL((k_mix_grad_W2<T, AY, GROUPS>), grid, dim3(kMixCols * GROUPS), 0, s,
+                               (const cplx<T> *)Tsp, (const cplx<T> *)VT, (const cplx<T> *)RT, (cplx<T> *)Gn,
+                               (cplx<T> *)Gp, g.N, g.M, g.Hy, g.Dy, KX, KXP, nper);
+            TNMF_LAUNCH_CHECK();
+            return TNMF_OK;
+        }
+    }
     const dim3 grid((unsigned)g.M, (unsigned)cdiv(KX, kMixCols), (unsigned)cdiv(ngroups, GROUPS));
     hipLaunchKernelGGL((k_mix_grad_W<T, AY, 1, GROUPS>), grid, dim3(kMixCols * GROUPS), 0, s, (const cplx<T> *)Tsp,
                        (const cplx<T> *)VT, (const cplx<T> *)RT, (cplx<T> *)Gn, (cplx<T> *)Gp, g.N, g.M, g.C, g.Hy, g.Dy,

@@ -155,7 +155,7 @@ __global__ void k_split_prep_W(Geo g, int NP, int NSLOT, int KB, const float *__
     }
 }
 
-template <bool FUSED, int AY, int NR4>
+template <bool FUSED, bool MULTI, int AY, int NR4>
 __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(Geo g, int tiles_y, int tiles_x, int ablate,
                                                             unsigned long long *dbg,
                                                             const float *__restrict__ V, const float *__restrict__ Rr,
@@ -190,11 +190,34 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
     // zero the whole window once: the spare row and the slack of every plane stay zero (finite) for good
     for (int i = threadIdx.x; i < Cfg::win / 16; i += kBlock) reinterpret_cast<u32x4 *>(Xw)[i] = u32x4{0, 0, 0, 0};
 
-    auto stage_W = [&](int c) {
+    // W image of one channel: global (L2-resident, pre-split by k_split_prep_W) -> LDS, 16 bytes per thread and piece, in
+    // chunks of up to 8 pieces whose loads are all issued before the first store (one memory round trip per chunk, not
+    // one per piece).  MULTI (several channels, compile time): the image changes every stage; the first chunk is loaded
+    // BEFORE the barrier that frees the previous image and stored behind it.
+    constexpr int NPW = (KB * 3 * 64 + kBlock - 1) / kBlock, WCH = 8, NWCH = (NPW + WCH - 1) / WCH;
+    u32x4 wtmp[WCH];
+    auto load_W = [&](int c, int chunk) {
         const u32x4 *src = Wimg + (size_t)(mt * g.C + c) * (KB * 3 * 64);
-        for (int i = threadIdx.x; i < KB * 3 * 64; i += kBlock) reinterpret_cast<u32x4 *>(Wl)[i] = src[i];
+#pragma unroll
+        for (int k = 0; k < WCH; ++k) {
+            const int i = threadIdx.x + (chunk * WCH + k) * kBlock;
+            if (chunk * WCH + k < NPW) wtmp[k] = src[i < KB * 3 * 64 ? i : 0];
+        }
     };
-    if (g.C == 1) stage_W(0);
+    auto store_W = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < WCH; ++k) {
+            const int i = threadIdx.x + (chunk * WCH + k) * kBlock;
+            if (chunk * WCH + k < NPW && i < KB * 3 * 64) reinterpret_cast<u32x4 *>(Wl)[i] = wtmp[k];
+        }
+    };
+    if (!MULTI) {
+#pragma unroll
+        for (int ch = 0; ch < NWCH; ++ch) {
+            load_W(0, ch);
+            store_W(ch);
+        }
+    }
 
     // Work assignment: a workgroup takes whole row blocks (8 rows x the full width of the shift plane of one sample) and
     // walks their column tiles left to right.  Rows of H are Hx floats long -- not a multiple of the 128-byte cache line --
@@ -341,9 +364,17 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
             for (int rb = 0; rb < SP_RB; ++rb) acc[rb][0] = acc[rb][1] = zero16();
         }
         SP_STAMP(0);     // stores of the previous epilogue issued, loop overhead
+        if (MULTI) load_W(c, 0);
         lds_barrier();   // every wave is done with the previous window and W image (first time: the zero fill)
         SP_STAMP(1);     // barrier 1
-        if (g.C > 1) stage_W(c);
+        if (MULTI) {
+            store_W(0);
+#pragma unroll
+            for (int ch = 1; ch < NWCH; ++ch) {
+                load_W(c, ch);
+                store_W(ch);
+            }
+        }
         if (!(TNMF_ABL(ablate) & 1)) commit();
         lds_barrier();
         SP_STAMP(2);     // commit + barrier 2
@@ -614,13 +645,21 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
     const size_t nw = (size_t)P * MT * 4;
     static const bool want_stamps = tnmf_diag_env("TNMF_HIP_STAMPS") != nullptr;   // -DTNMF_DIAG builds only
     if (want_stamps) TNMF_HIP_TRY(hipMalloc(&dbg, nw * 8 * sizeof(unsigned long long)));
-    if (fused)
-        hipLaunchKernelGGL((k_split_corr_W<true, AY, NR4>), grid, dim3(kBlock), Cfg::lds, s, g, tiles_y, tiles_x,
-                           ctx->ablate, dbg, V, R, (const u32x4 *)ctx->wimg, H_inout, (float *)nullptr, (float *)nullptr,
-                           reg);
-    else
-        hipLaunchKernelGGL((k_split_corr_W<false, AY, NR4>), grid, dim3(kBlock), Cfg::lds, s, g, tiles_y, tiles_x,
-                           ctx->ablate, dbg, V, R, (const u32x4 *)ctx->wimg, (float *)nullptr, neg, pos, 0.f);
+#define SPLIT_LAUNCH(FUSED_, MULTI_, H_, NEG_, POS_, REG_)                                                          \
+    hipLaunchKernelGGL((k_split_corr_W<FUSED_, MULTI_, AY, NR4>), grid, dim3(kBlock), Cfg::lds, s, g, tiles_y, tiles_x, \
+                       ctx->ablate, dbg, V, R, (const u32x4 *)ctx->wimg, H_, NEG_, POS_, REG_)
+    if (fused) {
+        if (g.C > 1)
+            SPLIT_LAUNCH(true, true, H_inout, (float *)nullptr, (float *)nullptr, reg);
+        else
+            SPLIT_LAUNCH(true, false, H_inout, (float *)nullptr, (float *)nullptr, reg);
+    } else {
+        if (g.C > 1)
+            SPLIT_LAUNCH(false, true, (float *)nullptr, neg, pos, 0.f);
+        else
+            SPLIT_LAUNCH(false, false, (float *)nullptr, neg, pos, 0.f);
+    }
+#undef SPLIT_LAUNCH
     TNMF_LAUNCH_CHECK();
     if (dbg) {
         TNMF_HIP_TRY(hipStreamSynchronize(s));
@@ -644,10 +683,14 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
 
 template <int AY, int NR4>
 int prepare_one() {
-    TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_split_corr_W<true, AY, NR4>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_split_corr_W<false, AY, NR4>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define SPLIT_ATTR(FUSED_, MULTI_)                                                              \
+    TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_split_corr_W<FUSED_, MULTI_, AY, NR4>,     \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    SPLIT_ATTR(true, true);
+    SPLIT_ATTR(true, false);
+    SPLIT_ATTR(false, true);
+    SPLIT_ATTR(false, false);
+#undef SPLIT_ATTR
     return TNMF_OK;
 }
 
