@@ -58,6 +58,9 @@ CONFIGS = {
     3: dict(N=256, C=1, D=(256, 256), M=32, A=(12, 12)),
     4: dict(N=256, C=3, D=(256, 256), M=32, A=(12, 12)),   # per-GPU shard of the 2048-sample problem
     5: dict(N=128, C=3, D=(512, 512), M=64, A=(16, 16)),   # per-GPU shard of the 1024-sample problem
+    # not a BASELINE config: config 3 with 245 x 245 samples, whose activation rows (256 floats) are whole cache lines --
+    # the alignment experiment of DESIGN.md 4c
+    6: dict(N=256, C=1, D=(245, 245), M=32, A=(12, 12)),
 }
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector = f32 MFMA
 PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)

@@ -304,6 +304,15 @@ int tnmf_hip_ctx_invalidate(tnmf_hip_ctx *ctx) {
 
 const char *tnmf_hip_ctx_last_path(const tnmf_hip_ctx *ctx) { return ctx ? ctx->last_path : "none"; }
 
+#ifdef TNMF_DIAG
+// diagnostic library only (not part of the ABI of include/tnmf_hip.h): change the ablation mask of a live context
+int tnmf_hip_diag_set_ablate(tnmf_hip_ctx *ctx, int mask) {
+    if (!ctx) return TNMF_E_NULL;
+    ctx->ablate = mask;
+    return TNMF_OK;
+}
+#endif
+
 int tnmf_hip_reconstruct(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *W, const void *H, void *R,
                          void *stream) {
     ENTER(ctx, geom);
