@@ -61,6 +61,8 @@ CONFIGS = {
     # not a BASELINE config: config 3 with 245 x 245 samples, whose activation rows (256 floats) are whole cache lines --
     # the alignment experiment of DESIGN.md 4c
     6: dict(N=256, C=1, D=(245, 245), M=32, A=(12, 12)),
+    # not a BASELINE config: long 1-D signals (config 1's kind of data at a size that is not launch-bound)
+    7: dict(N=2048, C=3, D=(500,), M=32, A=(64,)),
 }
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector = f32 MFMA
 PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
@@ -237,10 +239,9 @@ def main():
     F = conv_flops(cfg, n_local)
     Hs = tuple(d + a - 1 for d, a in zip(cfg['D'], cfg['A']))
     h_bytes = 4.0 * n_local * cfg['M'] * float(np.prod(Hs))
-    t_bytes = 0.0
-    if k == 2:   # row spectra of the FFT family: N*M*Hy*(Lx/2+1) complex64
-        Lx = next((L for L in (32, 48, 64, 96, 144, 192, 288, 384, 576) if L >= Hs[1]), 0)
-        t_bytes = 8.0 * n_local * cfg['M'] * Hs[0] * (Lx // 2 + 1)
+    # row spectra of the FFT family: N*M*Hy*(Lx/2+1) complex64; 1-D signals: one row per (sample, atom)
+    Lx = next((L for L in (32, 48, 64, 96, 144, 192, 288, 384, 576) if L >= Hs[-1]), 0)
+    t_bytes = 8.0 * n_local * cfg['M'] * (Hs[0] if k == 2 else 1) * (Lx // 2 + 1)
 
     # samples one kernel launch processes, as a fraction of the rank's samples (Cyclic-MU launches work on one batch)
     batch_size_g = args.batch_size if args.batch_size else max(1, n_global // 4)
@@ -326,7 +327,7 @@ def main():
     # direct-vs-FFT crossover of BASELINE.json configs[4].
     variants = {}
     fams = set(paths.values())
-    main_family = ('hybrid' if 'fft' in fams and (fams & {'mfma', 'split'}) else be.last_path)
+    main_family = ('hybrid' if 'fft' in fams and (fams & {'mfma', 'split', 'generic'}) else be.last_path)
     if 'split' in fams:
         main_family += '+split' if main_family != 'split' else ''
     if world == 1 and not args.no_fft_variant and k == 2:
@@ -404,8 +405,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
-                'workload': (f'2-D shift-invariant MU, full batch: ' if args.algorithm == 'full' else
-                             f'2-D shift-invariant MU, Cyclic-MU epochs (global batch {batch_size}): ') +
+                'workload': (f'{k}-D shift-invariant MU, full batch: ' if args.algorithm == 'full' else
+                             f'{k}-D shift-invariant MU, Cyclic-MU epochs (global batch {batch_size}): ') +
                             f'{n_local} samples x {cfg["C"]} ch x '
                             f'{"x".join(map(str, cfg["D"]))} per GPU, {cfg["M"]} atoms '
                             f'{"x".join(map(str, cfg["A"]))} (BASELINE.json configs[{args.config - 1}])',

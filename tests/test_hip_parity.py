@@ -461,6 +461,53 @@ def test_hybrid_dispatch_on_ragged_shapes(shape):
     assert relmax(be.to_ndarray(Hf), Ho) < 4 * tol and relmax(be.to_ndarray(Wf), Wo) < 4 * tol
 
 
+ONE_D_SHAPES = [
+    # N, C, D, M, A -- 1-D signals on the row-transform half of the FFT family (path='hybrid'): BASELINE config 1's
+    # geometry (three channels, atoms of 20), one channel, two channels with a ragged transform length
+    (10, 3, (60,), 8, (20,)),
+    (2, 1, (500,), 4, (16,)),
+    (3, 2, (301,), 5, (7,)),
+]
+
+
+@pytest.mark.parametrize('shape', ONE_D_SHAPES, ids=[f'{s[0]}x{s[1]}x{s[2][0]}_m{s[3]}_a{s[4][0]}' for s in ONE_D_SHAPES])
+def test_one_dimensional_signals_on_the_fft_rows(shape):
+    """1-D problems under path='hybrid': reconstruct and the W gradient are pointwise products of row spectra (own LDS
+    FFT kernels, k_mix_reconstruct / k_mix_grad_W_1d), the H update stays on the direct kernels -- against the float64
+    oracle, with the fused half steps chained so that the cached spectra are exercised."""
+    N, C, D, M, A = shape
+    rng = np.random.default_rng(N * 100 + M)
+    V = rng.random((N, C) + D)
+    Wn = rng.random((M, C) + A)
+    Wn /= Wn.sum(axis=-1, keepdims=True)
+    Hn = rng.random((N, M, D[0] + A[0] - 1))
+    be = make_backend(V.astype(np.float32), A, M, 'hybrid')
+    W, H = dev(Wn, np.float32), dev(Hn, np.float32)
+    tol = 2e-5
+    assert relmax(be.to_ndarray(be.reconstruct(W, H)), orc.reconstruct(Wn, Hn, 'c')) < tol
+    assert be.last_path == 'fft'
+    on, op = orc.gradient_H(V, Wn, Hn, slice(None), 'c')
+    neg, pos = be.reconstruction_gradient_H(V, W, H)
+    assert be.last_path == 'generic'
+    assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+    for s in (slice(None), slice(N - 1, N)):
+        on, op = orc.gradient_W(V, Wn, Hn, s, 'c')
+        neg, pos = be.reconstruction_gradient_W(V, W, H, s)
+        assert be.last_path == 'fft'
+        assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+    Hf, Wf = dev(Hn, np.float32), dev(Wn, np.float32)
+    Ho, Wo = Hn.copy(), Wn.copy()
+    for _ in range(2):
+        be.fused_update_H(V, Wf, Hf, slice(None), sparsity=0., eps=1e-9)
+        be.fused_update_W(V, Wf, Hf, slice(None), eps=1e-9)
+        on, op = orc.gradient_H(V, Wo, Ho, slice(None), 'c')
+        Ho = Ho * on / (op + 1e-9)
+        on, op = orc.gradient_W(V, Wo, Ho, slice(None), 'c')
+        Wo = Wo * on / (op + 1e-9)
+        Wo /= Wo.sum(axis=-1, keepdims=True)
+    assert relmax(be.to_ndarray(Hf), Ho) < 4 * tol and relmax(be.to_ndarray(Wf), Wo) < 4 * tol
+
+
 def test_kernel_families_agree_over_a_long_run_with_empty_regions():
     """120 float32 iterations on a sparse planted model with an exactly blank band (V == 0: both gradients vanish there,
     the hard case for a float32 frequency-domain update): the hybrid default and the pure FFT family must stay finite

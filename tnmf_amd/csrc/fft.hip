@@ -367,7 +367,12 @@ int prepare(tnmf_hip_ctx *ctx, const Geo &g, int dtype, Lay *l, bool window = fa
 }  // namespace
 
 bool fft_has(const Geo &g, int dtype) {
-    if (g.Dy == 1 && g.Ay == 1) return false;   // 1-D signals stay on the direct kernels
+    if (g.Dy == 1 && g.Ay == 1) {
+        // 1-D signals: the row-transform half of the family alone (float32, up to three channels): reconstruct and the W
+        // gradient are pointwise products of row spectra; the H update stays on the direct kernels (fft_grad_H /
+        // fft_update_H refuse 1-D problems)
+        return pick_len(g.Hx, dtype) != 0 && mixed_has_reconstruct(g, dtype) && mixed_has_grad_W(g, dtype);
+    }
     return pick_len(g.Hy, dtype) != 0 && pick_len(g.Hx, dtype) != 0;
 }
 
@@ -467,6 +472,7 @@ int grad_H_window(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, int 
 
 int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *neg,
                void *pos, hipStream_t s) {
+    if (g.Dy == 1 && g.Ay == 1) return TNMF_E_UNSUPPORTED;   // 1-D: row-transform half only (fft_has)
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l, true));
     CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));
@@ -492,6 +498,7 @@ int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
 
 int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *H,
                  double reg, hipStream_t s) {
+    if (g.Dy == 1 && g.Ay == 1) return TNMF_E_UNSUPPORTED;   // 1-D: row-transform half only (fft_has)
     Lay l;
     CHECK(prepare(ctx, g, dtype, &l, true));
     CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));

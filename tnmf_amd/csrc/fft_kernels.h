@@ -662,13 +662,17 @@ int set_lds_limit(K kernel, size_t bytes) {
     return TNMF_OK;
 }
 
+// the dynamic-LDS opt-in belongs to the (function, device) pair: one flag per device, not one per process
 #define TNMF_FFT_LAUNCH(kernel, grid, threads, lds)                         \
     do {                                                                    \
-        static bool attr_done = false;                                      \
-        if (!attr_done) {                                                   \
+        static unsigned long long attr_done = 0;                            \
+        int dev_ = 0;                                                       \
+        TNMF_HIP_TRY(hipGetDevice(&dev_));                                  \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                \
+        if (!(attr_done & bit_)) {                                          \
             const int _rc = set_lds_limit(kernel, (lds));                   \
             if (_rc != TNMF_OK) return _rc;                                 \
-            attr_done = true;                                               \
+            attr_done |= bit_;                                              \
         }                                                                   \
         hipLaunchKernelGGL(kernel, grid, dim3(threads), (lds), s, *a);      \
         TNMF_LAUNCH_CHECK();                                                \
@@ -683,6 +687,15 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
     constexpr size_t col_lds = (size_t)L * (LenCfg<L>::col_tile + 1) * sizeof(cplx<T>) + tw_bytes;
     constexpr size_t wide_lds = (size_t)L * 17 * sizeof(cplx<T>) + tw_bytes;
     if (row_tile * 2 + tw_bytes > 160 * 1024 || col_lds > 160 * 1024 || wide_lds > 160 * 1024) return TNMF_E_UNSUPPORTED;
+    // 1-D signals: planes of ONE row each.  The row kernels take tiles of 2 NB rows of one plane, so the planes are handed
+    // over as the rows of a single plane (contiguous either way: plane stride = one row).
+    FftArgs flat;
+    if ((op == kFftRowsFwd || op == kFftRowsInv) && a->rows == 1 && a->planes > 1) {
+        flat = *a;
+        flat.rows = a->planes;
+        flat.planes = 1;
+        a = &flat;
+    }
     const dim3 rgrid((unsigned)cdiv(a->rows, 2 * NB), (unsigned)a->planes);
     const unsigned tiles = (unsigned)cdiv(a->KX, LenCfg<L>::col_tile), wide_tiles = (unsigned)cdiv(a->KX, 16);
     switch (op) {

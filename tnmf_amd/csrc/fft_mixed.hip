@@ -108,9 +108,55 @@ __global__ __launch_bounds__(kMixCols *STRIPS, 2) void k_mix_reconstruct(const c
     }
 }
 
+// 1-D signals (one row per plane): OT[n,c,kx] = sum_m T[n,m,kx] * WT[m,c,kx] -- a thread per (sample, kx), all channels
+// of the sample in registers, the atom loop unrolled by four so that four loads of T are in flight.
+template <typename T, int CG, int SAMPLES>
+__global__ __launch_bounds__(kMixCols *SAMPLES) void k_mix_reconstruct_1d(const cplx<T> *Tsp, const cplx<T> *WT,
+                                                                        cplx<T> *OT, int N, int M, int C, int KX,
+                                                                        int KXP) {
+    const int col = threadIdx.x & (kMixCols - 1), sub = threadIdx.x / kMixCols;
+    const int kx = blockIdx.x * kMixCols + col, kxc = min(kx, KX - 1);
+    const int n = blockIdx.y * SAMPLES + sub, nc = min(n, N - 1);
+    cplx<T> acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = {0, 0};
+    const cplx<T> *tp = Tsp + (long)nc * M * KXP + kxc;
+    int m = 0;
+    for (; m + 4 <= M; m += 4) {
+        cplx<T> t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = tp[(long)(m + q) * KXP];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < CG; ++c) cfma(acc[c], t[q], WT[((long)(m + q) * C + min(c, C - 1)) * KXP + kxc]);
+    }
+    for (; m < M; ++m) {
+        const cplx<T> t = tp[(long)m * KXP];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) cfma(acc[c], t, WT[((long)m * C + min(c, C - 1)) * KXP + kxc]);
+    }
+    if (kx >= KX || n >= N) return;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        if (c >= C) break;
+        OT[((long)n * C + c) * KXP + kx] = acc[c];
+    }
+}
+
 template <typename T, int AY>
 int launch_mix_reconstruct(const void *Tsp, const void *WT, void *OT, const Geo &g, int KX, int KXP, hipStream_t s) {
     const unsigned tiles = (unsigned)cdiv(KX, kMixCols);
+    if constexpr (AY == 1) {
+        if (g.Dy == 1) {   // 1-D signals
+            constexpr int SAMPLES = 16;
+            hipLaunchKernelGGL((k_mix_reconstruct_1d<T, 3, SAMPLES>), dim3(tiles, (unsigned)cdiv(g.N, SAMPLES)),
+                               dim3(kMixCols * SAMPLES), 0, s, (const cplx<T> *)Tsp, (const cplx<T> *)WT, (cplx<T> *)OT,
+                               g.N, g.M, g.C, KX, KXP);
+            TNMF_LAUNCH_CHECK();
+            return TNMF_OK;
+        }
+    }
     if (g.C == 1) {
         constexpr int S = 16, STRIPS = 8;
         hipLaunchKernelGGL((k_mix_reconstruct<T, AY, 1, S, STRIPS>),
@@ -297,10 +343,56 @@ __global__ __launch_bounds__(kMixCols *GROUPS, 2) void k_mix_grad_W2(const cplx<
     }
 }
 
+// 1-D signals (one row per plane, AY == 1), up to CG channels per thread:
+//   GT[m,c,kx] = sum_n T[n,m,kx] * conj(VT[n,c,kx])   (and with RT); no lags along y, one entry per (sample, atom, kx)
+template <typename T, int CG, int GROUPS>
+__global__ __launch_bounds__(kMixCols *GROUPS) void k_mix_grad_W_1d(const cplx<T> *Tsp, const cplx<T> *VT, const cplx<T> *RT,
+                                                                  cplx<T> *Gn, cplx<T> *Gp, int N, int M, int C, int KX,
+                                                                  int KXP, int nper) {
+    const int col = threadIdx.x & (kMixCols - 1), sub = threadIdx.x / kMixCols;
+    const int kx = blockIdx.y * kMixCols + col, kxc = min(kx, KX - 1);
+    const int m = blockIdx.x, grp = blockIdx.z * GROUPS + sub;
+    cplx<T> an[CG], ap[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        an[c] = {0, 0};
+        ap[c] = {0, 0};
+    }
+    const int nbeg = grp * nper, nend = min(N, nbeg + nper);
+    for (int n = nbeg; n < nend; ++n) {
+        const cplx<T> t = Tsp[((long)n * M + m) * KXP + kxc];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const long o = ((long)n * C + min(c, C - 1)) * KXP + kxc;
+            cfmac(an[c], t, VT[o]);
+            cfmac(ap[c], t, RT[o]);
+        }
+    }
+    if (kx >= KX) return;
+    const long gsize = (long)M * C * KXP;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        if (c >= C) break;
+        const long o = (long)grp * gsize + ((long)m * C + c) * KXP + kx;
+        Gn[o] = an[c];
+        Gp[o] = ap[c];
+    }
+}
+
 template <typename T, int AY>
 int launch_mix_grad_W(const void *Tsp, const void *VT, const void *RT, void *Gn, void *Gp, const Geo &g, int KX,
                       int KXP, int ngroups, int nper, hipStream_t s) {
     constexpr int GROUPS = 4;
+    if constexpr (AY == 1) {
+        if (g.Dy == 1) {   // 1-D signals: all channels of an atom in one thread
+            const dim3 grid((unsigned)g.M, (unsigned)cdiv(KX, kMixCols), (unsigned)cdiv(ngroups, GROUPS));
+            hipLaunchKernelGGL((k_mix_grad_W_1d<T, 4, GROUPS>), grid, dim3(kMixCols * GROUPS), 0, s, (const cplx<T> *)Tsp,
+                               (const cplx<T> *)VT, (const cplx<T> *)RT, (cplx<T> *)Gn, (cplx<T> *)Gp, g.N, g.M, g.C, KX,
+                               KXP, nper);
+            TNMF_LAUNCH_CHECK();
+            return TNMF_OK;
+        }
+    }
     if constexpr (AY <= 12) {   // (taller atoms: the two-atom variant no longer fits the register file)
         if (g.C == 1) {
             const dim3 grid((unsigned)cdiv(g.M, 2), (unsigned)cdiv(KX, kMixCols), (unsigned)cdiv(ngroups, GROUPS));
@@ -346,8 +438,13 @@ int launch_mix_grad_W(const void *Tsp, const void *VT, const void *RT, void *Gn,
 // whose cost does not grow with C*Ay, are faster (measured with the three-channel variant of k_mix_reconstruct, which
 // is kept instantiated: config 4 reconstruct 2.5 -> 3.3 ms, config 5 11.0 -> 15.5 ms), and the W gradient's two
 // accumulator sets per channel no longer fit the registers.
-bool mixed_has_reconstruct(const Geo &g, int dtype) { return dtype == 0 && g.Ay <= 16 && g.C == 1; }
-bool mixed_has_grad_W(const Geo &g, int dtype) { return dtype == 0 && g.Ay <= 16 && g.C == 1; }
+// 1-D signals (Dy == Ay == 1): nothing to contract along y, so up to three / four channels fit as well.
+bool mixed_has_reconstruct(const Geo &g, int dtype) {
+    return dtype == 0 && g.Ay <= 16 && (g.C == 1 || (g.Dy == 1 && g.Ay == 1 && g.C <= 3));
+}
+bool mixed_has_grad_W(const Geo &g, int dtype) {
+    return dtype == 0 && g.Ay <= 16 && (g.C == 1 || (g.Dy == 1 && g.Ay == 1 && g.C <= 4));
+}
 
 int mixed_reconstruct(const Geo &g, const void *Tsp, const void *WT, void *OT, int KX, int KXP, hipStream_t s) {
     MIX_SWITCH(launch_mix_reconstruct, Tsp, WT, OT, g, KX, KXP, s);
