@@ -209,8 +209,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
     assert torch.cuda.is_available(), 'bench.py needs a GPU; the hip backend has no CPU path'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # one rank per GPU.  Rehearsal on a box with fewer GPUs than ranks (TNMF_BENCH_DIST_BACKEND=gloo): the ranks share the
+    # visible devices and the collective goes through gloo -- RCCL refuses two ranks on one device
+    dist_backend = os.environ.get('TNMF_BENCH_DIST_BACKEND', 'nccl')
+    dev_index = local_rank if dist_backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     group = None
     force_dist = os.environ.get('TNMF_BENCH_FORCE_DIST') == '1'   # exercise the RCCL path with a single rank
     if world > 1 or force_dist:
@@ -218,7 +222,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29531')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=device)   # nccl == RCCL on ROCm
+        if dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(dist_backend)
         group = dist.group.WORLD
 
     cfg = dict(CONFIGS[args.config])

@@ -245,3 +245,27 @@ def test_reference_inhibition_line_needs_backend_native_H():
     pos += 0.2 * g
     pos *= 0.8
     assert view.data_ptr() == H[1].data_ptr() and pos.shape == H.shape
+
+
+def test_bench_two_rank_path_rehearsal(tmp_path):
+    """bench.py's N > 1 path end to end with the real backend: two processes (torch.distributed.run) share the one GPU
+    of the test box, the collective goes through gloo (RCCL refuses two ranks on one device).  Not a performance number
+    -- it checks that the sharded bench runs, that both ranks take part and that the JSON line is well formed."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TNMF_BENCH_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1', '--config', '2', '--samples', '8', '--algorithm', 'cyclic', '--batch-size', '4']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0 and line['scaling'] == 'weak'
+    assert line['config']['global_samples'] == 16 and line['config']['algorithm'] == 'cyclic'
+    assert 'sample-sharded x2' in line['config']['parallelism']
