@@ -117,6 +117,18 @@ __device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, uns
     lo = __builtin_bit_cast(unsigned short, l);
 }
 
+// the same for two values at once, each result a packed pair (first value in the low half): one v_cvt_pk_bf16_f32 per
+// term instead of two conversions and a pack
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x2 lo, u32x2 hi) {
     const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(bf16x8, v);
@@ -302,21 +314,17 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
                 fr[e] = ok ? vb : 0.f;
             }
         }
-        unsigned t[6][7];
+        // element pairs (0,1) (2,3) (4,5) (6,-) of the six term arrays, converted two at a time
 #pragma unroll
-        for (int e = 0; e < 7; ++e) {
-            split3(fv[e], t[0][e], t[1][e], t[2][e]);
-            split3(fr[e], t[3][e], t[4][e], t[5][e]);
+        for (int k = 0; k < 4; ++k) {
+            split3_pair(fv[2 * k], k < 3 ? fv[2 * k + 1] : 0.f, tp[0][k], tp[1][k], tp[2][k]);
+            split3_pair(fr[2 * k], k < 3 ? fr[2 * k + 1] : 0.f, tp[3][k], tp[4][k], tp[5][k]);
         }
+        // the odd pairs (1,2) (3,4) (5,6): one funnel shift each
 #pragma unroll
-        for (int ar = 0; ar < 6; ++ar) {
+        for (int ar = 0; ar < 6; ++ar)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                tp[ar][k] = t[ar][2 * k] | (t[ar][2 * k + 1] << 16);
-                tq[ar][k] = t[ar][2 * k + 1] | (t[ar][2 * k + 2] << 16);
-            }
-            tp[ar][3] = t[ar][6];
-        }
+            for (int k = 0; k < 3; ++k) tq[ar][k] = (tp[ar][k] >> 16) | (tp[ar][k + 1] << 16);
     };
     auto commit = [&]() {
         if (threadIdx.x < Cfg::witems) {
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
         constexpr bool LAST = decltype(lastc)::value;
         int n, u0, v0, c;
         stage_coords(st, n, u0, v0, c);
-        if (c == 0) {
+        if (MULTI && c == 0) {   // (one channel: the first MFMA of every accumulator takes a zero C operand instead)
 #pragma unroll
             for (int rb = 0; rb < SP_RB; ++rb) acc[rb][0] = acc[rb][1] = zero16();
         }
@@ -472,7 +480,9 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
                 const bf16x8 bhi = __builtin_bit_cast(bf16x8, b[bb][0]);
                 const bf16x8 bmid = __builtin_bit_cast(bf16x8, b[bb][1]);
                 const bf16x8 blo = __builtin_bit_cast(bf16x8, b[bb][2]);
-                f32x16 d = acc[rb][x];       // D[atom][pixel] += W[atom][k] * X[k][pixel]
+                // D[atom][pixel] += W[atom][k] * X[k][pixel]; one channel: the first k block starts from zero (an inline
+                // constant C operand: no 64 register moves per stage to clear the accumulators)
+                f32x16 d = (!MULTI && kb == 0) ? zero16() : acc[rb][x];
                 d = mfma_bf16(bhi, alo, d);    // smallest terms first
                 d = mfma_bf16(blo, ahi, d);
                 d = mfma_bf16(bmid, amid, d);
@@ -498,35 +508,32 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
             //     rows of y; x = register r (bit 1 clear), y = register r + 2.
             // (b) register bit 0 <-> lane bit 3: lanes 8..15 of every row take the partner register from the lane 8 below,
             //     lanes 0..7 from the lane 8 above: two DPP moves (row_ror:8) under bank masks, no select.
+            // In-place inline asm on scalar copies of the accumulators: through the builtins hipcc spends two register
+            // moves per exchange on keeping operands it no longer needs.  (s_nop 1: two wait states between a VALU write
+            // of an operand and the permlane / DPP read, which hipcc does not insert inside asm.)
 #pragma unroll
             for (int rb = 0; rb < SP_RB; ++rb)
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
-                    unsigned w[16];
+                    float w[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float f = acc[rb][x][r];
-                        w[r] = __builtin_bit_cast(unsigned, f);
-                    }
+                    for (int r = 0; r < 16; ++r) w[r] = acc[rb][x][r];
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (!(r & 2)) {
-                            const auto sw = __builtin_amdgcn_permlane16_swap(w[r], w[r + 2], false, false);
-                            w[r] = sw[0];
-                            w[r + 2] = sw[1];
-                        }
+                        if (!(r & 2)) asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(w[r]), "+v"(w[r + 2]));
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if (!(r & 1)) {
-                            const unsigned a0 = w[r], a1 = w[r + 1];
-                            w[r] = __builtin_amdgcn_update_dpp(a0, a1, 0x128, 0xF, 0xC, false);       // lanes 8..15: a1 of lane-8
-                            w[r + 1] = __builtin_amdgcn_update_dpp(a1, a0, 0x128, 0xF, 0x3, false);   // lanes 0..7: a0 of lane+8
+                            const float a0 = w[r];
+                            asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xc"   // lanes 8..15: a1 of lane-8
+                                : "+v"(w[r])
+                                : "v"(w[r + 1]));
+                            asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0x3"   // lanes 0..7: a0 of lane+8
+                                : "+v"(w[r + 1])
+                                : "v"(a0));
                         }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned wr_ = w[r];
-                        acc[rb][x][r] = __builtin_bit_cast(float, wr_);
-                    }
+                    for (int r = 0; r < 16; ++r) acc[rb][x][r] = w[r];
                 }
             SP_STAMP(6);   // register <-> lane exchanges
             if (FUSED && !interior) {
@@ -563,8 +570,10 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float nv = acc[rb][0][4 * q + e], pv_ = acc[rb][1][4 * q + e];
-                        // H * neg / (pos + reg), hardware reciprocal (1 ulp): inside the f32 parity budget
-                        const float ov = FUSED ? __fdividef(hv[rb][4 * q + e] * nv, pv_ + reg) : 0.f;
+                        // H * neg / (pos + reg) with the hardware reciprocal (v_rcp_f32, 1 ulp; pos + reg > 0): ~2 ulp, inside
+                        // the f32 parity budget.  (__fdividef compiles to the full IEEE division sequence here: ten
+                        // instructions per element.)
+                        const float ov = FUSED ? hv[rb][4 * q + e] * nv * __builtin_amdgcn_rcpf(pv_ + reg) : 0.f;
                         o4[e] = __builtin_bit_cast(unsigned, ov);
                         n4[e] = __builtin_bit_cast(unsigned, nv);
                         q4[e] = __builtin_bit_cast(unsigned, pv_);
