@@ -17,6 +17,7 @@
 namespace {
 
 const int kLens[] = {32, 48, 64, 96, 144, 192, 288, 384, 576};
+constexpr int kMixMaxGroups = 128;   // partial-sum slots of the mixed W-gradient kernel (Gn / Gp)
 
 int pick_len(int h, int dtype) {
     for (int L : kLens)
@@ -107,9 +108,9 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
     l->SWf = take(nSW);
     l->TW = take((size_t)2 * g.M * g.C * g.Ay * kxp * c);
     l->Wt = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
-    // partial W-gradient spectra: [groups][M*C][Ly][KXP] for the column-transform kernel, [<= 64 groups][M*C][Ay][KXP]
-    // for the mixed kernel
-    const size_t nG = std::max(nSW * l->ngroups, (size_t)64 * g.M * g.C * g.Ay * kxp * c);
+    // partial W-gradient spectra: [groups][M*C][Ly][KXP] for the column-transform kernel, [<= kMixMaxGroups groups]
+    // [M*C][Ay][KXP] for the mixed kernel
+    const size_t nG = std::max(nSW * l->ngroups, (size_t)kMixMaxGroups * g.M * g.C * g.Ay * kxp * c);
     l->Gn = take(nG);
     l->Gp = take(nG);
     l->Gs = take(nSW * 2);
@@ -165,18 +166,32 @@ __global__ void k_fft_prep_W(const T *W, T *out0, T *out1, int planes, int Ay, i
     out1[(long)p * per + (Ay - 1 - ay) * Ax + (Ax - 1 - ax)] = v;
 }
 
-// out = scale * sum over groups, in group order (deterministic)
+// out = scale * sum over groups, in group order (deterministic); blockIdx.y picks the gradient (neg / pos).  The loads of
+// four groups are issued together, the additions keep the group order.
 template <typename T>
-__global__ void k_fft_sum_groups(const cplx<T> *parts, cplx<T> *out, long count, int ngroups, double scale) {
+__global__ __launch_bounds__(64) void k_fft_sum_groups(const cplx<T> *parts0, const cplx<T> *parts1, cplx<T> *out0,
+                                                      cplx<T> *out1, long count, int ngroups, double scale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
+    const cplx<T> *parts = blockIdx.y ? parts1 : parts0;
     double re = 0, im = 0;
-    for (int gidx = 0; gidx < ngroups; ++gidx) {
+    int gidx = 0;
+    for (; gidx + 4 <= ngroups; gidx += 4) {
+        cplx<T> v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = parts[(gidx + k) * count + i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            re += (double)v[k].x;
+            im += (double)v[k].y;
+        }
+    }
+    for (; gidx < ngroups; ++gidx) {
         const cplx<T> v = parts[gidx * count + i];
         re += (double)v.x;
         im += (double)v.y;
     }
-    out[i] = {(T)(re * scale), (T)(im * scale)};
+    (blockIdx.y ? out1 : out0)[i] = {(T)(re * scale), (T)(im * scale)};
 }
 
 // neg/pos[m,c,a] = corr[m,c,A-1-a]  (the flip of NumPy.py:85,90)
@@ -525,6 +540,31 @@ int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, cons
     return TNMF_OK;
 }
 
+// Sample groups (= partial sums) of the mixed W gradient.  Its grid is (atom blocks) x (kx tiles) x (groups / 4) workgroups
+// of ONE wave, and the register budget lets two waves share a SIMD: the grid should fill the chip's 2 * 4 * CUs wave
+// slots a whole number of times -- at config 3, 64 groups gave 2560 waves for 2048 slots, i.e. a second round on a
+// quarter of the chip (0.89 ms; 128 groups: 2.5 rounds of half-size waves).  More groups cost partial-sum traffic.
+int mix_groups(const tnmf_hip_ctx *ctx, const Geo &g, const Lay &l) {
+    const long slots = 2L * 4 * (ctx->num_cu > 0 ? ctx->num_cu : 256);
+    const long per_group_block = (long)(g.C == 1 && g.Ay <= 12 ? cdiv(g.M, 2) : g.M) * cdiv(l.KX, 16);
+    int best = 32;
+    double best_cost = 1e30;
+    for (int cand = 32; cand <= kMixMaxGroups; cand *= 2) {
+        int ng = g.N < cand ? g.N : cand;
+        const int nper = cdiv(g.N, ng);
+        ng = cdiv(g.N, nper);
+        const double rounds = (double)(per_group_block * cdiv(ng, 4)) / (double)slots;
+        const double whole = rounds <= 1.0 ? 1.0 : (double)(long)(rounds + 0.999999);
+        // time ~ whole rounds of (work / rounds) each; partial sums: 3 % of the kernel per 32 groups (measured at 64)
+        const double cost = whole / rounds + 0.03 * (cand / 32);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = cand;
+        }
+    }
+    return best;
+}
+
 int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *H, void *neg,
                void *pos, bool nonneg, hipStream_t s) {
     Lay l;
@@ -536,11 +576,10 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
     if (mixed) {
         // transform along x only; the Ay lags along y are accumulated directly (fft_mixed.hip)
         CHECK(forward_rows(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.RT), s));
-        // sample groups = partial sums: the two-atom kernel (atoms up to 12 rows) has half as many atom blocks, so it
-        // takes twice the groups to keep ~2.5 waves per SIMD in the grid
-        int ng_want = g.Ay <= 12 ? 64 : 32;
+        // sample groups = partial sums (mix_groups below)
+        int ng_want = mix_groups(ctx, g, l);
         if (const char *e = tnmf_diag_env("TNMF_MIX_GROUPS")) ng_want = atoi(e);   // diagnostic builds only
-        ng_want = ng_want < 1 ? 1 : (ng_want > 64 ? 64 : ng_want);                 // Gn/Gp hold 64 groups
+        ng_want = ng_want < 1 ? 1 : (ng_want > kMixMaxGroups ? kMixMaxGroups : ng_want);
         int ng = g.N < ng_want ? g.N : ng_want;
         const int nper = cdiv(g.N, ng);
         ng = cdiv(g.N, nper);
@@ -548,13 +587,11 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
         CHECK(mixed_grad_W(g, at(ctx, l.T), at(ctx, l.VT), at(ctx, l.RT), at(ctx, l.Gn), at(ctx, l.Gp), l.KX, l.KXP,
                            ngpad, nper, s));
         const long count = (long)g.M * g.C * g.Ay * l.KXP;
-        for (int which = 0; which < 2; ++which) {
-            const char *parts = at(ctx, which ? l.Gp : l.Gn);
-            char *out = at(ctx, l.TW) + which * (size_t)count * l.csz;   // [2*M*C][Ay][KXP]
-            hipLaunchKernelGGL(k_fft_sum_groups<float>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
-                               (const cplx<float> *)parts, (cplx<float> *)out, count, ngpad, 1.0 / l.Lx);
-            TNMF_LAUNCH_CHECK();
-        }
+        char *out = at(ctx, l.TW);   // [2*M*C][Ay][KXP]
+        hipLaunchKernelGGL(k_fft_sum_groups<float>, dim3((unsigned)((count + 63) / 64), 2), dim3(64), 0, s,
+                           (const cplx<float> *)at(ctx, l.Gn), (const cplx<float> *)at(ctx, l.Gp), (cplx<float> *)out,
+                           (cplx<float> *)(out + (size_t)count * l.csz), count, ngpad, 1.0 / l.Lx);
+        TNMF_LAUNCH_CHECK();
     } else {
         CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
         if (use_resident(l)) {
@@ -576,15 +613,17 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
         const long count = (long)g.M * g.C * l.Ly * l.KXP;
         const size_t sbytes = (size_t)count * l.csz;
         const double scale = 1.0 / ((double)l.Ly * l.Lx);
-        for (int which = 0; which < 2; ++which) {
-            const char *parts = at(ctx, which ? l.Gp : l.Gn);
-            char *out = at(ctx, l.Gs) + which * sbytes;
+        {
+            char *out = at(ctx, l.Gs);
+            const dim3 grid((unsigned)((count + 63) / 64), 2);
             if (dtype == 0)
-                hipLaunchKernelGGL(k_fft_sum_groups<float>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
-                                   (const cplx<float> *)parts, (cplx<float> *)out, count, l.ngroups, scale);
+                hipLaunchKernelGGL(k_fft_sum_groups<float>, grid, dim3(64), 0, s, (const cplx<float> *)at(ctx, l.Gn),
+                                   (const cplx<float> *)at(ctx, l.Gp), (cplx<float> *)out, (cplx<float> *)(out + sbytes),
+                                   count, l.ngroups, scale);
             else
-                hipLaunchKernelGGL(k_fft_sum_groups<double>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
-                                   (const cplx<double> *)parts, (cplx<double> *)out, count, l.ngroups, scale);
+                hipLaunchKernelGGL(k_fft_sum_groups<double>, grid, dim3(64), 0, s, (const cplx<double> *)at(ctx, l.Gn),
+                                   (const cplx<double> *)at(ctx, l.Gp), (cplx<double> *)out,
+                                   (cplx<double> *)(out + sbytes), count, l.ngroups, scale);
             TNMF_LAUNCH_CHECK();
         }
         FftArgs b = base_args(g, l);

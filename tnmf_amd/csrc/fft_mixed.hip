@@ -282,25 +282,48 @@ __global__ __launch_bounds__(kMixCols *GROUPS, 2) void k_mix_grad_W2(const cplx<
             an[q][a] = {0, 0};
             ap[q][a] = {0, 0};
         }
-    const int nbeg = grp * nper, nend = min(N, nbeg + nper);
+    // Addresses: a wave holds GROUPS sample groups, so the sample index differs from lane to lane.  Every address is
+    // split into a wave-uniform part -- a buffer descriptor based at (sample nr of the block's first group, atom) plus
+    // a scalar row offset -- and a per-lane 32-bit byte offset that never changes (group of the lane, kx).  With whole
+    // per-lane 64-bit pointers the address arithmetic (20 64-bit vector operations per row next to 96 packed
+    // multiply-adds) cost a third of the kernel.  The host checks that the offsets fit 31 bits.
+    static_assert(sizeof(cplx<T>) == 8, "float spectra");
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
     const long tplane = (long)Hy * KXP, vplane = (long)Dy * KXP;
+    const int nbeg0 = blockIdx.z * GROUPS * nper, nbeg = nbeg0 + sub * nper;
+    const int lane_t = (int)(((long)sub * nper * M * tplane + kxc) * 8);
+    const int lane_v = (int)(((long)sub * nper * vplane + kxc) * 8);
+    const int rowb = KXP * 8;   // bytes per row of spectra
+    auto ld = [](const __amdgpu_buffer_rsrc_t &rs, int lane_off, int row_off) {
+        const u32x2v w = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, row_off, 0);
+        const unsigned re = w[0], im = w[1];   // (bit_cast straight on a vector element reads element 0: hipcc 7.2)
+        return cplx<T>{__builtin_bit_cast(float, re), __builtin_bit_cast(float, im)};
+    };
 #pragma unroll 1
-    for (int n = nbeg; n < nend; ++n) {
-        const cplx<T> *tp0 = Tsp + ((long)n * M + m0) * tplane, *tp1 = Tsp + ((long)n * M + m1) * tplane;
-        const cplx<T> *vp = VT + (long)n * vplane, *rp = RT + (long)n * vplane;
+    for (int nr = 0; nr < nper; ++nr) {
+        if (nbeg0 + nr >= N) break;    // (uniform) no group of this block has a sample nr
+        if (nbeg + nr >= N) continue;  // this lane's group has run out of samples
+        const cplx<T> *tb = Tsp + ((long)(nbeg0 + nr) * M + m0) * tplane;
+        const __amdgpu_buffer_rsrc_t t0 = __builtin_amdgcn_make_buffer_rsrc((void *)tb, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t t1 =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(tb + (long)(m1 - m0) * tplane), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t vb =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(VT + (long)(nbeg0 + nr) * vplane), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(RT + (long)(nbeg0 + nr) * vplane), 0, 0x7fffffff, 0x00020000);
         cplx<T> t[MA][RS], v[VS], r[VS];
         // rows 0 .. RS-2 of the H spectra, rows 0 .. P-1 of V^/R^ (row indices clamped: always legal addresses)
 #pragma unroll
         for (int i = 0; i < RS - 1; ++i) {
-            const unsigned o = (unsigned)(min(i, Hy - 1) * KXP + kxc);
-            t[0][i] = tp0[o];
-            t[1][i] = tp1[o];
+            const int o = min(i, Hy - 1) * rowb;
+            t[0][i] = ld(t0, lane_t, o);
+            t[1][i] = ld(t1, lane_t, o);
         }
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const unsigned o = (unsigned)(min(i, Dy - 1) * KXP + kxc);
-            v[i] = vp[o];
-            r[i] = rp[o];
+            const int o = min(i, Dy - 1) * rowb;
+            v[i] = ld(vb, lane_v, o);
+            r[i] = ld(rb, lane_v, o);
         }
 #pragma unroll 1
         for (int yb = 0; yb < Dy; yb += RS) {
@@ -311,12 +334,12 @@ __global__ __launch_bounds__(kMixCols *GROUPS, 2) void k_mix_grad_W2(const cplx<
                 if (y >= Dy) break;   // wave-uniform
                 // fetch: H row y + RS - 1 into the slot row y - 1 left, V^/R^ row y + P into the slot row y - 1 left
                 {
-                    const unsigned o = (unsigned)(min(y + RS - 1, Hy - 1) * KXP + kxc);
-                    t[0][(i + RS - 1) % RS] = tp0[o];
-                    t[1][(i + RS - 1) % RS] = tp1[o];
-                    const unsigned ov = (unsigned)(min(y + P, Dy - 1) * KXP + kxc);
-                    v[(i + P) % VS] = vp[ov];
-                    r[(i + P) % VS] = rp[ov];
+                    const int o = min(y + RS - 1, Hy - 1) * rowb;
+                    t[0][(i + RS - 1) % RS] = ld(t0, lane_t, o);
+                    t[1][(i + RS - 1) % RS] = ld(t1, lane_t, o);
+                    const int ov = min(y + P, Dy - 1) * rowb;
+                    v[(i + P) % VS] = ld(vb, lane_v, ov);
+                    r[(i + P) % VS] = ld(rb, lane_v, ov);
                 }
                 const cplx<T> vy = v[i % VS], ry = r[i % VS];
 #pragma unroll
@@ -394,7 +417,10 @@ int launch_mix_grad_W(const void *Tsp, const void *VT, const void *RT, void *Gn,
         }
     }
     if constexpr (AY <= 12) {   // (taller atoms: the two-atom variant no longer fits the register file)
-        if (g.C == 1) {
+        // per-lane byte offsets of the two-atom kernel: (group within the block) * nper samples of row spectra, plus
+        // a scalar row offset -- they must stay below 2^31 (the single-atom kernel below has no such limit)
+        const long span = ((long)(GROUPS - 1) * nper * g.M + 2) * g.Hy * KXP * 8;
+        if (g.C == 1 && span < (1L << 31)) {
             const dim3 grid((unsigned)cdiv(g.M, 2), (unsigned)cdiv(KX, kMixCols), (unsigned)cdiv(ngroups, GROUPS));
             hipLaunchKernelGGL((k_mix_grad_W2<T, AY, GROUPS>), grid, dim3(kMixCols * GROUPS), 0, s,
                                (const cplx<T> *)Tsp, (const cplx<T> *)VT, (const cplx<T> *)RT, (cplx<T> *)Gn,
