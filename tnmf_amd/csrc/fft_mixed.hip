@@ -61,33 +61,45 @@ __global__ __launch_bounds__(kMixCols *STRIPS, 2) void k_mix_reconstruct(const c
     for (int c = 0; c < CG; ++c)
 #pragma unroll
         for (int y = 0; y < S; ++y) acc[c][y] = {0, 0};
-    // element offsets inside a plane do not depend on the atom: uniform plane base + 32-bit per-thread offset.
-    // The rows of the next atom are fetched while the current ones are multiplied (two register sets).
-    unsigned toff[S + AY - 1], woff[AY];
-#pragma unroll
-    for (int r = 0; r < S + AY - 1; ++r) toff[r] = (unsigned)(min(y0 + r, Hy - 1) * KXP + kxc);
-#pragma unroll
-    for (int a = 0; a < AY; ++a) woff[a] = (unsigned)((AY - 1 - a) * KXP + kxc);
+    // Addresses: a buffer descriptor per plane (wave-uniform, scalar registers), a scalar row offset, and ONE per-lane
+    // byte offset (first row of the strip, kx) that never changes -- no vector address arithmetic and no offset
+    // registers.  Rows past the plane (y0 + r >= Hy: only under outputs that are never stored) fail the descriptor's
+    // range check and read as zero.  The rows of the next atom are fetched while the current ones are multiplied.
+    static_assert(sizeof(cplx<T>) == 8, "float spectra");
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    auto ld = [](const __amdgpu_buffer_rsrc_t &rs, int lane_off, int row_off) {
+        const u32x2v w2 = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, row_off, 0);
+        const unsigned re = w2[0], im = w2[1];   // (bit_cast straight on a vector element reads element 0: hipcc 7.2)
+        return cplx<T>{__builtin_bit_cast(float, re), __builtin_bit_cast(float, im)};
+    };
+    const int rowb = KXP * 8;
     const long tplane = (long)Hy * KXP, wplane = (long)AY * KXP;
+    const int lane_t = (y0 * KXP + kxc) * 8, lane_w = kxc * 8;
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)WT, 0, (int)((long)M * C * wplane * 8), 0x00020000);
+    auto plane = [&](int m) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(Tsp + ((long)n * M + m) * tplane), 0, (int)(tplane * 8),
+                                                 0x00020000);
+    };
     cplx<T> t[S + AY - 1], tn[S + AY - 1];
     {
-        const cplx<T> *tp = Tsp + (long)n * M * tplane;
+        const __amdgpu_buffer_rsrc_t rs = plane(0);
 #pragma unroll
-        for (int r = 0; r < S + AY - 1; ++r) t[r] = tp[toff[r]];
+        for (int r = 0; r < S + AY - 1; ++r) t[r] = ld(rs, lane_t, r * rowb);
     }
 #pragma unroll 1
     for (int m = 0; m < M; ++m) {
         cplx<T> w[CG][AY];
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
-            const cplx<T> *wp = WT + ((long)m * C + min(c, C - 1)) * wplane;
+            const int wbase = ((m * C + min(c, C - 1)) * AY) * rowb;
 #pragma unroll
-            for (int a = 0; a < AY; ++a) w[c][a] = wp[woff[a]];
+            for (int a = 0; a < AY; ++a) w[c][a] = ld(wrs, lane_w, wbase + (AY - 1 - a) * rowb);
         }
         {
-            const cplx<T> *tp = Tsp + ((long)n * M + min(m + 1, M - 1)) * tplane;
+            const __amdgpu_buffer_rsrc_t rs = plane(min(m + 1, M - 1));
 #pragma unroll
-            for (int r = 0; r < S + AY - 1; ++r) tn[r] = tp[toff[r]];
+            for (int r = 0; r < S + AY - 1; ++r) tn[r] = ld(rs, lane_t, r * rowb);
         }
 #pragma unroll
         for (int c = 0; c < CG; ++c)
