@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TNMF_HIP_ABI_VERSION 3
+#define TNMF_HIP_ABI_VERSION 4
 
 enum {
     TNMF_OK = 0,
@@ -37,7 +37,8 @@ enum {
     TNMF_E_GEOM = -2,      /* bad geometry (ndim, sizes <= 0, atom larger than supported) */
     TNMF_E_DTYPE = -3,     /* dtype not 0/1 */
     TNMF_E_WORKSPACE = -4, /* workspace allocation failed */
-    TNMF_E_UNSUPPORTED = -5
+    TNMF_E_UNSUPPORTED = -5,
+    TNMF_E_STRIDE = -6     /* h_row_stride > shift width, and the kernel family this call dispatches to wants C-contiguous H */
 };
 
 typedef struct tnmf_hip_ctx tnmf_hip_ctx;
@@ -50,6 +51,13 @@ typedef struct {
     int D[2];  /* sample shape; ndim == 1 uses D[0] only */
     int A[2];  /* atom shape;   ndim == 1 uses A[0] only */
     int dtype; /* 0 = f32, 1 = f64 */
+    /* Row stride of H in elements; 0 (or the shift width D[last] + A[last] - 1) = C-contiguous, as the reference's arrays
+     * are.  A larger value describes activations whose rows are padded to whole cache lines: H[n,m,y,x] at
+     * ((n*M + m)*Hy + y)*h_row_stride + x, the plane and sample strides following from it.  Supported where H is
+     * streamed by the FFT family and the split kernel (the default dispatch of float32 problems the hybrid covers);
+     * every other kernel family answers TNMF_E_STRIDE and touches nothing -- the caller then passes a contiguous copy.
+     * Outputs shaped like H (neg / pos of tnmf_hip_grad_H) are always C-contiguous. */
+    int h_row_stride;
 } tnmf_hip_geom;
 
 /* Kernel family selection (tnmf_hip_ctx_set_path): AUTO picks the MFMA kernels where the shape allows and, for float32
@@ -73,6 +81,10 @@ enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_
 int tnmf_hip_ctx_set_split(tnmf_hip_ctx *ctx, int enable);
 
 int tnmf_hip_abi_version(void);
+/* Row stride (elements) this context would like H of `geom` to have: the shift width itself, or -- when the H update runs
+ * on the split kernel next to the FFT family -- the shift width rounded up to 32 floats, so that every 32-pixel tile of a
+ * row is exactly one 128-byte line (267-float rows make each tile straddle two lines: 1.7x the H traffic, measured). */
+int tnmf_hip_ctx_h_row_stride(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int *stride_out);
 const char *tnmf_hip_strerror(int code);
 
 /* One context per device: caches device properties and owns the scratch (R, split-K partials). */

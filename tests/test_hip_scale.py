@@ -273,3 +273,89 @@ def test_bench_two_rank_path_rehearsal(tmp_path):
     assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0 and line['scaling'] == 'weak'
     assert line['config']['global_samples'] == 16 and line['config']['algorithm'] == 'cyclic'
     assert 'sample-sharded x2' in line['config']['parallelism']
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# row-padded activations (tnmf_hip_geom.h_row_stride)
+# ---------------------------------------------------------------------------------------------------------------
+def _padded_like(Hc, ld):
+    """A view with the values of the contiguous [N, M, Hy, Hx] tensor Hc in storage whose rows are ld elements long."""
+    store = torch.zeros(tuple(Hc.shape[:3]) + (ld,), dtype=Hc.dtype, device=Hc.device)
+    Hp = store[..., :Hc.shape[3]]
+    Hp.copy_(Hc)
+    return Hp
+
+
+def test_row_padded_activations_match_contiguous():
+    """What initialize() allocates for the hybrid dispatch -- activation rows padded to whole 128-byte lines, H a view
+    of that storage -- gives the SAME bits as C-contiguous activations in every primitive and in both fused half steps;
+    a kernel family that wants contiguous activations (path='mfma') answers TNMF_E_STRIDE and the backend goes through a
+    copy, with the in-place update landing in the padded tensor."""
+    rng = np.random.default_rng(21)
+    N, C, D, M, A = 4, 1, (96, 80), 32, (12, 12)
+    V = rng.random((N, C) + D).astype(np.float32)
+    Wn = rng.random((M, C) + A).astype(np.float32)
+    Hn = rng.random((N, M, D[0] + A[0] - 1, D[1] + A[1] - 1)).astype(np.float32)
+    for path, family in (('auto', 'split'), ('mfma', 'mfma')):
+        be = HIP_Backend(path=path)
+        np.random.seed(1)
+        W0, H0 = be.initialize(V, A, M, None, (-2, -1))
+        if path == 'auto':   # the backend's own H is padded: 91 -> 96 floats per row
+            assert not H0.is_contiguous() and H0.stride(2) == 96 and H0.stride(1) == H0.shape[2] * 96
+            assert tuple(H0.shape) == Hn.shape
+        else:
+            assert H0.is_contiguous()
+        W = torch.from_numpy(Wn).cuda()
+        Hc = torch.from_numpy(Hn).cuda()
+        Hp = _padded_like(Hc, 96)
+        assert not Hp.is_contiguous()
+        Rc, Rp = be.reconstruct(W, Hc), be.reconstruct(W, Hp)
+        assert torch.equal(Rc, Rp)
+        gc, gp = be.reconstruction_gradient_W(V, W, Hc), be.reconstruction_gradient_W(V, W, Hp)
+        assert torch.equal(gc[0], gp[0]) and torch.equal(gc[1], gp[1])
+        hc, hp = be.reconstruction_gradient_H(V, W, Hc), be.reconstruction_gradient_H(V, W, Hp)
+        assert hp[0].is_contiguous() and torch.equal(hc[0], hp[0]) and torch.equal(hc[1], hp[1])
+        assert be.reconstruction_energy(V, W, Hc) == be.reconstruction_energy(V, W, Hp)
+        Hc2, Hp2 = Hc.clone(), _padded_like(Hc, 96)
+        for _ in range(2):   # the second round runs on what the library may have cached about the first
+            be.fused_update_H(V, W, Hc2, slice(None), sparsity=0.05, eps=1e-9)
+            assert be.last_path == family
+            be.fused_update_H(V, W, Hp2, slice(None), sparsity=0.05, eps=1e-9)
+            assert be.last_path == family
+            assert torch.equal(Hc2, Hp2)
+            Wc, Wp = W.clone(), W.clone()
+            be.fused_update_W(V, Wc, Hc2, slice(None), eps=1e-9)
+            be.fused_update_W(V, Wp, Hp2, slice(None), eps=1e-9)
+            assert torch.equal(Wc, Wp)
+        # the pad columns of the storage never leak into results: poison them and repeat one reconstruct
+        Hp2._base[..., 91:] = float('nan')
+        assert torch.equal(be.reconstruct(W, Hp2), be.reconstruct(W, Hc2))
+        # a mini-batch slice of the padded tensor is still the padded layout
+        be.fused_update_H(V, W, Hc2, slice(1, 3), sparsity=0., eps=1e-9)
+        Hp3 = _padded_like(Hc, 96)
+        Hp3.copy_(Hp2)
+        Hc3 = Hp2.contiguous()
+        be.fused_update_H(V, W, Hp3, slice(1, 3), sparsity=0., eps=1e-9)
+        be.fused_update_H(V, W, Hc3, slice(1, 3), sparsity=0., eps=1e-9)
+        assert torch.equal(Hp3, Hc3)
+        del be
+
+
+def test_front_end_runs_on_row_padded_activations():
+    """fit() on the default dispatch: the activations the front end holds are the padded view; W, H and the energy agree
+    with the float64 oracle as they do for contiguous activations, and nmf.H comes back as a plain contiguous ndarray."""
+    oracle_threads()
+    N, C, D, M, A = 4, 1, (96, 80), 32, (12, 12)
+    V = planted_V(N, C, D, M, A, seed=5)
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=M, atom_shape=A, backend='hip')
+    nmf.fit(V, n_iterations=5, sparsity_H=0.02, progress_callback=lambda *_: True)
+    assert not nmf._H.is_contiguous() and nmf._H.stride(2) == 96
+    H = nmf.H
+    assert isinstance(H, np.ndarray) and H.flags['C_CONTIGUOUS'] and H.shape == (N, M, 107, 91)
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c').fit(V.astype(np.float64), n_iterations=5, sparsity_H=0.02)
+    dW, dH = relmax(nmf.W, ref.W), relmax(H, ref.H)
+    gap = abs(nmf._energy_function() - ref.energy()) / ref.energy()
+    print(f'padded rows: dW={dW:.2e} dH={dH:.2e} gap={gap:.2e}')
+    assert dW < 1e-5 and dH < 1e-5 and gap < 1e-5, (dW, dH, gap)

@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libtnmf_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/tnmf_hip.h declares
 EXPORTS = (
@@ -20,7 +20,7 @@ EXPORTS = (
     'tnmf_hip_grad_H', 'tnmf_hip_grad_W', 'tnmf_hip_mu_update', 'tnmf_hip_normalize_W', 'tnmf_hip_energy',
     'tnmf_hip_convolve_multi_1d', 'tnmf_hip_update_H', 'tnmf_hip_grad_W_fused', 'tnmf_hip_apply_W',
     'tnmf_hip_pad_H', 'tnmf_hip_fold_H', 'tnmf_hip_ctx_set_cache', 'tnmf_hip_ctx_invalidate',
-    'tnmf_hip_ctx_set_split',
+    'tnmf_hip_ctx_set_split', 'tnmf_hip_ctx_h_row_stride',
 )
 
 MODES = {'valid': 0, 'full': 1, 'circular': 2, 'reflect': 3}
@@ -31,7 +31,11 @@ PATHS = {'auto': 0, 'generic': 1, 'mfma': 2, 'fft': 3, 'hybrid': 4, 'split': 5}
 class Geom(ctypes.Structure):
     """tnmf_hip_geom"""
     _fields_ = [('ndim', ctypes.c_int), ('N', ctypes.c_int), ('M', ctypes.c_int), ('C', ctypes.c_int),
-                ('D', ctypes.c_int * 2), ('A', ctypes.c_int * 2), ('dtype', ctypes.c_int)]
+                ('D', ctypes.c_int * 2), ('A', ctypes.c_int * 2), ('dtype', ctypes.c_int),
+                ('h_row_stride', ctypes.c_int)]
+
+
+E_STRIDE = -6   # TNMF_E_STRIDE: the kernel family of this call wants C-contiguous H
 
 
 class TnmfHipError(RuntimeError):
@@ -67,6 +71,7 @@ def load() -> ctypes.CDLL:
     lib.tnmf_hip_ctx_set_path.argtypes = [vp, ci]
     lib.tnmf_hip_ctx_set_cache.argtypes = [vp, ci]
     lib.tnmf_hip_ctx_set_split.argtypes = [vp, ci]
+    lib.tnmf_hip_ctx_h_row_stride.argtypes = [vp, gp, ctypes.POINTER(ci)]
     lib.tnmf_hip_ctx_invalidate.argtypes = [vp]
     lib.tnmf_hip_ctx_last_path.restype = ctypes.c_char_p
     lib.tnmf_hip_ctx_last_path.argtypes = [vp]
@@ -99,7 +104,8 @@ def check(code: int, where: str) -> None:
         raise TnmfHipError(code, where, text.decode() if text else '?')
 
 
-def make_geom(n: int, m: int, c: int, sample_shape: Sequence[int], atom_shape: Sequence[int], dtype_code: int) -> Geom:
+def make_geom(n: int, m: int, c: int, sample_shape: Sequence[int], atom_shape: Sequence[int], dtype_code: int,
+              h_row_stride: int = 0) -> Geom:
     k = len(atom_shape)
     if k not in (1, 2) or len(sample_shape) != k:
         raise NotImplementedError('the hip backend supports 1 or 2 shift dimensions')
@@ -108,4 +114,5 @@ def make_geom(n: int, m: int, c: int, sample_shape: Sequence[int], atom_shape: S
     for i in range(k):
         g.D[i] = int(sample_shape[i])
         g.A[i] = int(atom_shape[i])
+    g.h_row_stride = int(h_row_stride)   # 0: C-contiguous activations
     return g

@@ -200,16 +200,53 @@ class HIP_Backend(Backend):
     def _timed(self, name: str):
         return _EventSpan(self, name)
 
-    def _geom(self, n: int, n_atoms: int):
-        return _lib.make_geom(n, n_atoms, self.n_channels, self._sample_shape, self.atom_shape, self._dtype_code)
+    def _geom(self, n: int, n_atoms: int, h_row_stride: int = 0):
+        return _lib.make_geom(n, n_atoms, self.n_channels, self._sample_shape, self.atom_shape, self._dtype_code,
+                              h_row_stride)
 
     def _check_W(self, W: torch.Tensor):
         assert W.is_cuda and W.is_contiguous() and W.dtype == self._torch_dtype
         assert tuple(W.shape[1:]) == (self.n_channels,) + self.atom_shape
 
     def _check_H(self, H: torch.Tensor, n_atoms: int):
-        assert H.is_cuda and H.is_contiguous() and H.dtype == self._torch_dtype
+        assert H.is_cuda and H.dtype == self._torch_dtype
         assert tuple(H.shape[1:]) == (n_atoms,) + self._transform_shape
+
+    # Activations may live in storage whose rows are padded to whole cache lines (initialize() asks the library:
+    # tnmf_hip_ctx_h_row_stride); the tensor the front end holds is then a VIEW of that storage -- every torch operation
+    # of the reference's front end works on it unchanged -- and the C ABI is told the row stride (tnmf_hip_geom).
+    @staticmethod
+    def _row_stride(H: torch.Tensor) -> Optional[int]:
+        """Row stride (elements) of a C-contiguous or row-padded [N, M, *shift] tensor; None for any other layout."""
+        if H.is_contiguous():
+            return 0
+        if H.dim() != 4 or H.stride(3) != 1:
+            return None
+        ld = H.stride(2)
+        n, m, hy, hx = H.shape
+        ok = ld >= hx and (m <= 1 or H.stride(1) == hy * ld) and (n <= 1 or H.stride(0) == m * hy * ld)
+        if hy <= 1:   # (no row stride to read off a single row)
+            return None
+        return ld if ok else None
+
+    def _call_H(self, Hs: torch.Tensor, inplace: bool, call) -> bool:
+        """call(H tensor, row stride) -> return code of a library function that reads (inplace: updates) Hs.  A
+        row-padded Hs goes in as it is; when the kernel family of the call wants C-contiguous activations
+        (TNMF_E_STRIDE: nothing has been touched) or the layout is something else, a contiguous copy goes in instead and,
+        for an in-place call, is copied back.  Returns whether a copy was used (the library then saw a temporary: the
+        caller drops what it cached about it)."""
+        ld = self._row_stride(Hs)
+        if ld is not None:
+            rc, where = call(Hs, ld)
+            if not (rc == _lib.E_STRIDE and ld != 0):
+                _lib.check(rc, where)
+                return False
+        Hc = Hs.contiguous()
+        rc, where = call(Hc, 0)
+        _lib.check(rc, where)
+        if inplace:
+            Hs.copy_(Hc)
+        return True
 
     def _local(self, s: slice) -> slice:
         """Slices address this rank's resident samples (all samples when there is no process group)."""
@@ -238,7 +275,9 @@ class HIP_Backend(Backend):
         """Activations of this mode -> the padded tensor every kernel works on (identity for 'valid')."""
         if self._mode == 0:
             return H
-        assert H.is_contiguous() and tuple(H.shape[2:]) == self._transform_shape
+        if not H.is_contiguous():
+            H = H.contiguous()
+        assert tuple(H.shape[2:]) == self._transform_shape
         Hp = torch.empty(tuple(H.shape[:2]) + self._padded_shape, dtype=H.dtype, device=H.device)
         g = self._geom(H.shape[0], H.shape[1])
         _lib.check(self._lib.tnmf_hip_pad_H(self._ctx, ctypes.byref(g), self._mode, _ptr(H), _ptr(Hp), self._stream()),
@@ -273,7 +312,18 @@ class HIP_Backend(Backend):
         n0, n1 = self._shard = sharding.shard_bounds(N, self._rank, self._world)
         with torch.cuda.device(self._device):
             self._V_dev = torch.as_tensor(np.ascontiguousarray(V[n0:n1])).to(self._device)
-            H = torch.empty((n1 - n0, n_atoms) + self._transform_shape, dtype=self._torch_dtype, device=self._device)
+            ld = ctypes.c_int(0)
+            if self._mode == 0 and len(atom_shape) == 2 and n1 > n0:
+                _lib.check(self._lib.tnmf_hip_ctx_h_row_stride(self._ctx, ctypes.byref(self._geom(n1 - n0, n_atoms)),
+                                                               ctypes.byref(ld)), 'tnmf_hip_ctx_h_row_stride')
+            if ld.value > self._transform_shape[-1]:
+                # rows padded to whole 128-byte lines (zeros; never read as data): H is a view of the padded storage
+                store = torch.zeros((n1 - n0, n_atoms, self._transform_shape[0], ld.value), dtype=self._torch_dtype,
+                                    device=self._device)
+                H = store[..., :self._transform_shape[-1]]
+            else:
+                H = torch.empty((n1 - n0, n_atoms) + self._transform_shape, dtype=self._torch_dtype,
+                                device=self._device)
             if self._init_mode == 'device':
                 H.uniform_(0, 1).neg_().add_(1)
             else:
@@ -301,14 +351,12 @@ class HIP_Backend(Backend):
         """R = H (*) W, 'valid' part (reference: NumPy.py:122-132) -> tnmf_hip_reconstruct."""
         self._check_W(W)
         self._foreign_H()
-        if not H.is_contiguous():
-            H = H.contiguous()
         self._check_H(H, W.shape[0])
         H = self._pad(H)
         R = torch.empty((H.shape[0], self.n_channels) + self._sample_shape, dtype=self._torch_dtype, device=self._device)
-        g = self._geom(H.shape[0], W.shape[0])
-        _lib.check(self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(H), _ptr(R),
-                                                  self._stream()), 'tnmf_hip_reconstruct')
+        self._call_H(H, False, lambda Hc, ld: (self._lib.tnmf_hip_reconstruct(
+            self._ctx, ctypes.byref(self._geom(Hc.shape[0], W.shape[0], ld)), _ptr(W), _ptr(Hc), _ptr(R),
+            self._stream()), 'tnmf_hip_reconstruct'))
         return R
 
     def reconstruction_gradient_H(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone):
@@ -320,10 +368,11 @@ class HIP_Backend(Backend):
         Hs, Vs = H[ls], self._V_dev[ls]
         self._check_H(Hs, W.shape[0])
         Hs = self._pad(Hs)
-        neg, pos = torch.empty_like(Hs), torch.empty_like(Hs)
-        g = self._geom(Hs.shape[0], W.shape[0])
-        _lib.check(self._lib.tnmf_hip_grad_H(self._ctx, ctypes.byref(g), _ptr(Vs), None, _ptr(W), _ptr(Hs),
-                                             _ptr(neg), _ptr(pos), self._stream()), 'tnmf_hip_grad_H')
+        neg = torch.empty(Hs.shape, dtype=Hs.dtype, device=Hs.device)   # (C-contiguous whatever the layout of H)
+        pos = torch.empty(Hs.shape, dtype=Hs.dtype, device=Hs.device)
+        self._call_H(Hs, False, lambda Hc, ld: (self._lib.tnmf_hip_grad_H(
+            self._ctx, ctypes.byref(self._geom(Hc.shape[0], W.shape[0], ld)), _ptr(Vs), None, _ptr(W), _ptr(Hc),
+            _ptr(neg), _ptr(pos), self._stream()), 'tnmf_hip_grad_H'))
         return self._fold(neg), self._fold(pos)
 
     def _local_grad_W(self, W, H, s) -> torch.Tensor:
@@ -335,19 +384,27 @@ class HIP_Backend(Backend):
             self._validate_H_cache(Hs)
         Hs = self._pad(Hs)
         negpos = torch.empty_like(self._negpos)
-        g = self._geom(Hs.shape[0], W.shape[0])
         Rs = self._R_scratch[ls] if Hs.shape[0] else None
-        r_valid = 0
-        if self._timeline is not None and Hs.shape[0]:
-            with self._timed('reconstruct'):
-                _lib.check(self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(Hs), _ptr(Rs),
-                                                          self._stream()), 'tnmf_hip_reconstruct')
-            r_valid = 1
-        with self._timed('grad_W'):
-            _lib.check(self._lib.tnmf_hip_grad_W_fused(self._ctx, ctypes.byref(g), _ptr(Vs), _ptr(W), _ptr(Hs),
-                                                       _ptr(Rs), r_valid, _ptr(negpos), self._stream()),
-                       'tnmf_hip_grad_W_fused')
-        if self._mode == 0 and Hs.shape[0]:
+
+        def run(Hc, ld):
+            g = self._geom(Hc.shape[0], W.shape[0], ld)
+            r_valid = 0
+            if self._timeline is not None and Hc.shape[0]:
+                with self._timed('reconstruct'):
+                    rc = self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(Hc), _ptr(Rs),
+                                                        self._stream())
+                if rc != 0:
+                    return rc, 'tnmf_hip_reconstruct'
+                r_valid = 1
+            with self._timed('grad_W'):
+                rc = self._lib.tnmf_hip_grad_W_fused(self._ctx, ctypes.byref(g), _ptr(Vs), _ptr(W), _ptr(Hc), _ptr(Rs),
+                                                     r_valid, _ptr(negpos), self._stream())
+            return rc, 'tnmf_hip_grad_W_fused'
+
+        copied = self._call_H(Hs, False, run)
+        if copied:
+            self._foreign_H()   # the spectra the library may have kept belong to a temporary
+        elif self._mode == 0 and Hs.shape[0]:
             self._note_H_cache(Hs)
         return negpos
 
@@ -366,9 +423,9 @@ class HIP_Backend(Backend):
         self._check_H(H, W.shape[0])
         H = self._pad(H)
         out = ctypes.c_double(0.0)
-        g = self._geom(H.shape[0], W.shape[0])
-        _lib.check(self._lib.tnmf_hip_energy(self._ctx, ctypes.byref(g), _ptr(self._V_dev), _ptr(W), _ptr(H),
-                                             ctypes.byref(out), self._stream()), 'tnmf_hip_energy')
+        self._call_H(H, False, lambda Hc, ld: (self._lib.tnmf_hip_energy(
+            self._ctx, ctypes.byref(self._geom(Hc.shape[0], W.shape[0], ld)), _ptr(self._V_dev), _ptr(W), _ptr(Hc),
+            ctypes.byref(out), self._stream()), 'tnmf_hip_energy'))
         if self._world > 1:
             t = torch.tensor([out.value], dtype=torch.float64, device=self._device)
             self._all_reduce(t)
@@ -396,7 +453,9 @@ class HIP_Backend(Backend):
         axes = tuple(a % arr.ndim for a in axes)
         if axes != tuple(range(arr.ndim - k, arr.ndim)) or len(kernels) != k:
             raise NotImplementedError('the hip backend convolves along the shift axes only')
-        assert arr.is_cuda and arr.is_contiguous()
+        assert arr.is_cuda
+        if not arr.is_contiguous():   # (e.g. row-padded activations)
+            arr = arr.contiguous()
         out = torch.empty_like(arr)
         tmp = torch.empty_like(arr) if k == 2 else None
         ks = [np.ascontiguousarray(kk, dtype=np.float64) for kk in kernels]
@@ -411,16 +470,19 @@ class HIP_Backend(Backend):
     @staticmethod
     def to_ndarray(arr: torch.Tensor) -> np.ndarray:
         """Device tensor -> host ndarray (with a process group: this rank's shard of H / R)."""
-        return arr.detach().cpu().numpy()
+        return np.ascontiguousarray(arr.detach().cpu().numpy())
 
     # -- optional hooks used by the front-end ---------------------------------------------------------------
     def multiplicative_update(self, arr: torch.Tensor, neg: torch.Tensor, pos: torch.Tensor, regularization: float):
         """pos += reg (in place); arr = arr * neg / pos  (reference: TransformInvariantNMF.py:232-235)."""
-        assert arr.is_contiguous() and neg.is_contiguous() and pos.is_contiguous()
+        assert neg.is_contiguous() and pos.is_contiguous()
         assert arr.shape == neg.shape == pos.shape
-        _lib.check(self._lib.tnmf_hip_mu_update(self._ctx, self._dtype_code, _ptr(arr), _ptr(neg), _ptr(pos),
-                                                float(regularization), arr.numel(), self._stream()),
+        flat = arr if arr.is_contiguous() else arr.contiguous()   # (a flat elementwise kernel: row-padded H goes through a copy)
+        _lib.check(self._lib.tnmf_hip_mu_update(self._ctx, self._dtype_code, _ptr(flat), _ptr(neg), _ptr(pos),
+                                                float(regularization), flat.numel(), self._stream()),
                    'tnmf_hip_mu_update')
+        if flat is not arr:
+            arr.copy_(flat)
 
     def fused_update_H(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone, sparsity: float = 0.,
                        eps: float = 1e-9) -> None:
@@ -436,20 +498,28 @@ class HIP_Backend(Backend):
             neg, pos = self.reconstruction_gradient_H(V, W, H, s)
             self.multiplicative_update(Hs, neg, pos, eps + (sparsity if sparsity > 0 else 0.))
             return
-        g = self._geom(Hs.shape[0], W.shape[0])
         Rs = self._R_scratch[ls]
-        r_valid = 0
         self._validate_H_cache(Hs)
-        if self._timeline is not None:
-            with self._timed('reconstruct'):
-                _lib.check(self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(Hs), _ptr(Rs),
-                                                          self._stream()), 'tnmf_hip_reconstruct')
-            r_valid = 1
-        with self._timed('update_H'):
-            _lib.check(self._lib.tnmf_hip_update_H(self._ctx, ctypes.byref(g), _ptr(Vs), _ptr(W), _ptr(Hs), _ptr(Rs),
-                                                   r_valid, float(eps), float(sparsity), self._stream()),
-                       'tnmf_hip_update_H')
-        self._note_H_cache(Hs)
+
+        def run(Hc, ld):
+            g = self._geom(Hc.shape[0], W.shape[0], ld)
+            r_valid = 0
+            if self._timeline is not None:
+                with self._timed('reconstruct'):
+                    rc = self._lib.tnmf_hip_reconstruct(self._ctx, ctypes.byref(g), _ptr(W), _ptr(Hc), _ptr(Rs),
+                                                        self._stream())
+                if rc != 0:
+                    return rc, 'tnmf_hip_reconstruct'
+                r_valid = 1
+            with self._timed('update_H'):
+                rc = self._lib.tnmf_hip_update_H(self._ctx, ctypes.byref(g), _ptr(Vs), _ptr(W), _ptr(Hc), _ptr(Rs),
+                                                 r_valid, float(eps), float(sparsity), self._stream())
+            return rc, 'tnmf_hip_update_H'
+
+        if self._call_H(Hs, True, run):
+            self._foreign_H()   # the library updated (and kept spectra of) a temporary copy
+        else:
+            self._note_H_cache(Hs)
 
     def apply_W(self, W: torch.Tensor, negpos: torch.Tensor, eps: float = 1e-9) -> None:
         """W = W * neg / (pos + eps), then normalise over the atom axes (TransformInvariantNMF.py:232-238)."""

@@ -33,6 +33,8 @@ int to_geo(const tnmf_hip_geom *in, Geo *g) {
         return TNMF_E_GEOM;
     g->Hy = g->Dy + g->Ay - 1;
     g->Hx = g->Dx + g->Ax - 1;
+    g->Hs = in->h_row_stride > 0 ? in->h_row_stride : g->Hx;
+    if (g->Hs < g->Hx) return TNMF_E_GEOM;
     return TNMF_OK;
 }
 
@@ -148,6 +150,7 @@ int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, co
         // AUTO only chose the family for speed: when its workspace does not fit, the direct kernels still do the job
         if (!(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
     }
+    if (g.Hs != g.Hx) return TNMF_E_STRIDE;   // the direct families read C-contiguous H
     if (use_mfma(ctx, g, dtype, kReconstruct)) {
         ctx->last_path = "mfma";
         return mfma_reconstruct(ctx, g, (const float *)W, (const float *)H, (float *)R, s);
@@ -172,6 +175,7 @@ int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const v
         if (rc == TNMF_OK) ctx->last_path = "split";
         if (rc != TNMF_E_UNSUPPORTED) return rc;
     }
+    if (fused && g.Hs != g.Hx) return TNMF_E_STRIDE;   // (nothing has been written yet)
     if (use_mfma(ctx, g, dtype, kCorrW)) {
         ctx->last_path = "mfma";
         return mfma_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio, (float *)neg,
@@ -196,6 +200,7 @@ int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, con
         const int rc = fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, true, s);
         if (!(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
     }
+    if (g.Hs != g.Hx) return TNMF_E_STRIDE;
     if (use_mfma(ctx, g, dtype, kCorrH)) {
         ctx->last_path = "mfma";
         P = mfma_corr_H_chunks(ctx, g);
@@ -215,6 +220,21 @@ extern "C" {
 
 int tnmf_hip_abi_version(void) { return TNMF_HIP_ABI_VERSION; }
 
+int tnmf_hip_ctx_h_row_stride(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int *stride_out) {
+    if (!ctx || !stride_out) return TNMF_E_NULL;
+    Geo g;
+    const int rc = to_geo(geom, &g);
+    if (rc != TNMF_OK) return rc;
+    const int dtype = geom->dtype;
+    *stride_out = g.Hx;
+    // padded rows pay where the split kernel reads and writes H in 32-pixel tiles and every other reader of H is the
+    // FFT family's row transform; a whole number of 128-byte lines per row
+    const bool hybrid = ctx->path == TNMF_PATH_AUTO || ctx->path == TNMF_PATH_HYBRID;
+    if (hybrid && g.N > 0 && use_fft_hybrid(ctx, g, dtype) && use_split(ctx, g, dtype) && !fft_takes_H(ctx, g, dtype))
+        *stride_out = (int)align_up((size_t)g.Hx, 32);
+    return TNMF_OK;
+}
+
 const char *tnmf_hip_strerror(int code) {
     switch (code) {
         case TNMF_OK: return "ok";
@@ -223,6 +243,7 @@ const char *tnmf_hip_strerror(int code) {
         case TNMF_E_DTYPE: return "tnmf_hip: dtype must be 0 (f32) or 1 (f64)";
         case TNMF_E_WORKSPACE: return "tnmf_hip: scratch allocation failed";
         case TNMF_E_UNSUPPORTED: return "tnmf_hip: shape not supported by the selected kernel family";
+        case TNMF_E_STRIDE: return "tnmf_hip: this kernel family wants C-contiguous H (h_row_stride == shift width)";
         default: break;
     }
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
@@ -422,6 +443,7 @@ int tnmf_hip_pad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const
     ENTER(ctx, geom);
     if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
     if (g.N > 0 && (!H || !Hpad)) return TNMF_E_NULL;
+    if (g.Hs != g.Hx) return TNMF_E_STRIDE;
     return launch_pad_fold(ctx, g, dtype, mode, false, H, Hpad, s);
 }
 

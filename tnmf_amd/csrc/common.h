@@ -13,6 +13,7 @@ struct Geo {
     int Dy, Dx;  // sample shape
     int Ay, Ax;  // atom shape
     int Hy, Hx;  // shift (activation) shape: D + A - 1
+    int Hs;      // row stride of H in elements (>= Hx; == Hx: C-contiguous)
 };
 
 // state of the FFT kernel family (fft.hip): its own workspace and the cache of the row spectra of H

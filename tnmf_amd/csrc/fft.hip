@@ -285,7 +285,7 @@ bool T_is_current(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *
     const FftState &f = ctx->fft;
     return f.cache_enabled && f.T_valid && f.T_owner == H && f.T_dtype == dtype && f.T_geo.N == g.N &&
            f.T_geo.M == g.M && f.T_geo.C == g.C && f.T_geo.Dy == g.Dy && f.T_geo.Dx == g.Dx && f.T_geo.Ay == g.Ay &&
-           f.T_geo.Ax == g.Ax;
+           f.T_geo.Ax == g.Ax && f.T_geo.Hs == g.Hs;
 }
 
 void T_mark(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
@@ -355,8 +355,8 @@ int rows_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const vo
     a.planes = g.N * g.M;
     a.rows = g.Hy;
     a.cols = g.Hx;
-    a.ld_src = g.Hx;
-    a.ps_src = (long)g.Hy * g.Hx;
+    a.ld_src = g.Hs;   // rows of H may be padded (tnmf_hip_geom.h_row_stride)
+    a.ps_src = (long)g.Hy * g.Hs;
     a.ps_dst = (long)g.Hy * l.KXP;
     CHECK(l.rowf(kFftRowsFwd, dtype, &a, s));
     T_mark(ctx, g, dtype, H);
@@ -518,7 +518,7 @@ int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, cons
     CHECK(prepare(ctx, g, dtype, &l, true));
     CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));
     ctx->fft.T_valid = ctx->fft.SH_valid = false;
-    const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hx, tplane = (size_t)g.M * g.Hy * l.KXP;
+    const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hs, tplane = (size_t)g.M * g.Hy * l.KXP;
     for (int n0 = 0; n0 < g.N; n0 += l.chunk) {
         const int cnt = g.N - n0 < l.chunk ? g.N - n0 : l.chunk;
         CHECK(grad_H_window(ctx, g, l, dtype, n0, cnt, s));
@@ -530,8 +530,8 @@ int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, cons
         a.planes = cnt * g.M;
         a.rows = g.Hy;
         a.cols = g.Hx;
-        a.ld_dst = g.Hx;
-        a.ps_src = (long)g.Hy * g.Hx;
+        a.ld_dst = g.Hs;
+        a.ps_src = (long)g.Hy * g.Hs;
         a.ps_dst = (long)g.Hy * l.KXP;
         a.reg = reg;
         CHECK(l.rowf(kFftRowsMu, dtype, &a, s));

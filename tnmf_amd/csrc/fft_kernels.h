@@ -126,16 +126,38 @@ __global__ __launch_bounds__(NT) void k_fft_rows_fwd(FftArgs a) {
     make_twiddles<T, L>(tw, tid, NT);
     const T *src = static_cast<const T *>(a.src0) + plane * a.ps_src;
     T *xr = reinterpret_cast<T *>(x);
+    if (tid < L) {
+        const int xc = min(tid, a.cols - 1);
+        T v[R2];
 #pragma unroll
-    for (int sl = 0; sl < XS; ++sl) {
-        const int xx = tid + sl * NT;
-        if (xx < L) {
-            const int xc = min(xx, a.cols - 1);
-            T v[R2];
+        for (int r = 0; r < R2; ++r) v[r] = src[(long)min(y0 + r, a.rows - 1) * a.ld_src + xc];
 #pragma unroll
-            for (int r = 0; r < R2; ++r) v[r] = src[(long)min(y0 + r, a.rows - 1) * a.ld_src + xc];
+        for (int r = 0; r < R2; ++r) xr[tid * (2 * BS) + r] = (y0 + r < a.rows && tid < a.cols) ? v[r] : (T)0;
+    }
+    if constexpr (XS > 2) {   // long transforms: further column slots
 #pragma unroll
-            for (int r = 0; r < R2; ++r) xr[xx * (2 * BS) + r] = (y0 + r < a.rows && xx < a.cols) ? v[r] : (T)0;
+        for (int sl = 1; sl < XS; ++sl) {
+            const int xx = tid + sl * NT;
+            if (xx < L) {
+                const int xc = min(xx, a.cols - 1);
+                T v[R2];
+#pragma unroll
+                for (int r = 0; r < R2; ++r) v[r] = src[(long)min(y0 + r, a.rows - 1) * a.ld_src + xc];
+#pragma unroll
+                for (int r = 0; r < R2; ++r) xr[xx * (2 * BS) + r] = (y0 + r < a.rows && xx < a.cols) ? v[r] : (T)0;
+            }
+        }
+    } else if constexpr (XS == 2) {
+        // columns beyond the block size: the few that hold data (267 - 256 at config 3) are dealt over ALL threads, row
+        // by row -- as a second column slot they were 2 R2 more loads for the first wave alone -- the rest is padding
+        const int rem = a.cols > NT ? a.cols - NT : 0, c0 = NT + rem;
+        for (int idx = tid; idx < rem * R2; idx += NT) {
+            const int r = idx / rem, c = idx - r * rem;
+            xr[(NT + c) * (2 * BS) + r] = y0 + r < a.rows ? src[(long)(y0 + r) * a.ld_src + NT + c] : (T)0;
+        }
+        for (int idx = tid; idx < (L - c0) * R2; idx += NT) {
+            const int c = idx / R2, r = idx - c * R2;
+            xr[(c0 + c) * (2 * BS) + r] = (T)0;
         }
     }
     __syncthreads();

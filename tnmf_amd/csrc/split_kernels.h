@@ -397,18 +397,22 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
         // goes through fully used cache lines with the fewest possible instructions (8 loads + 8 stores per wave and stage).
         // H of sample n is addressed through a buffer descriptor (base = first plane of the sample, size = M planes) with
         // 32-bit byte offsets; its range check drops the atoms beyond M of a partial atom tile.
-        const unsigned plane4 = (unsigned)g.Hy * g.Hx * 4;   // bytes of one atom plane
+        // Row stride: H itself may have padded rows (g.Hs > g.Hx: every 32-pixel tile is then one whole 128-byte line and
+        // the pad columns are part of the last tile -- they are read, updated and written like pixels, 0 stays 0, nobody
+        // else looks at them); the separate neg / pos outputs of the unfused call are C-contiguous.
+        const int hs = FUSED ? g.Hs : g.Hx;
+        const unsigned plane4 = (unsigned)g.Hy * hs * 4;     // bytes of one atom plane
         const int p0 = v0 + 4 * (j & 7);                     // first of this lane's four pixels
-        const int p0c = p0 < g.Hx - 4 ? p0 : g.Hx - 4;
-        const bool interior = v0 + SP_TX <= g.Hx;            // wave-uniform: whole tile inside the row
+        const int p0c = p0 < hs - 4 ? p0 : hs - 4;
+        const bool interior = v0 + SP_TX <= hs;              // wave-uniform: whole tile inside the (padded) row
         const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(Hio + (size_t)n * g.M * g.Hy * g.Hx), 0, (int)(g.M * plane4), 0x00020000);
+            (void *)(Hio + (size_t)n * g.M * g.Hy * hs), 0, (int)(g.M * plane4), 0x00020000);
         unsigned hoff[SP_RB];   // byte offset of (atom of register group 0, row, first pixel), start column clamped
 #pragma unroll
         for (int rb = 0; rb < SP_RB; ++rb) {
             const int u = u0 + wave * SP_RB + rb;
             hoff[rb] = (unsigned)(mt * 32 + ((j >> 3) & 3) + 4 * h) * plane4 +
-                       ((unsigned)(u < g.Hy ? u : g.Hy - 1) * g.Hx + p0c) * 4;
+                       ((unsigned)(u < g.Hy ? u : g.Hy - 1) * hs + p0c) * 4;
         }
         // H values of this lane's outputs, consumed only in the epilogue: UNCONDITIONAL 16-byte loads on clamped, always
         // legal addresses, issued one per MFMA group from inside the loop (mem_slot)
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
             // The arithmetic consumes every prefetched H value UNCONDITIONALLY (only the stores are predicated): a load
             // whose result is used on some paths only stays "pending" for hipcc's wait-count pass at the loop back edge,
             // and the next stage's H loads into the same registers would then wait for the window prefetch in between.
-            const size_t sample = (size_t)n * g.M * g.Hy * g.Hx;
+            const size_t sample = (size_t)n * g.M * g.Hy * hs;
             const __amdgpu_buffer_rsrc_t nrsrc =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(neg + (FUSED ? 0 : sample)), 0, (int)(g.M * plane4), 0x00020000);
             const __amdgpu_buffer_rsrc_t prsrc =
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (urow && p0 + e < g.Hx) {
+                            if (urow && p0 + e < hs) {
                                 const unsigned ow = o4[e], nw = n4[e], qw = q4[e];
                                 if (FUSED) {
                                     __builtin_amdgcn_raw_buffer_store_b32(ow, hrsrc, off + 4 * e, 0, 0);
