@@ -38,7 +38,7 @@ be = nmf._backend
 W, H = nmf._W, nmf._H
 R = be.reconstruct(W, H)
 H0 = H.clone()
-g = be._geom(H.shape[0], W.shape[0])
+g = be._geom(H.shape[0], W.shape[0], be._row_stride(H) or 0)   # (the backend's H has row-padded storage)
 p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
 be._lib.tnmf_hip_diag_set_ablate.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for mask in masks:
