@@ -342,8 +342,6 @@ def main():
         legs = [('mfma', 'direct_variant', True), ('fft', 'fft_variant', True)]
         if 'split' in fams:
             legs.insert(0, (args.path, 'exact_f32_variant', False))   # same dispatch, H update on the exact f32 MFMA
-        elif main_family == 'fft' and args.path == 'auto':
-            legs.insert(0, ('hybrid', 'hybrid_split_variant', True))  # what AUTO passed over: H update on the split kernel
         for vpath, label, vsplit in legs:
             if vsplit and (vpath == main_family or args.path == vpath):
                 continue

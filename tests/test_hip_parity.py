@@ -563,20 +563,16 @@ def test_auto_dispatch_at_baseline_sizes(C, D, M, A):
     R = be.reconstruct(W, H)
     assert be.last_path == 'fft'
     nH, pH = be.reconstruction_gradient_H(V, W, H)
-    # H gradient: bf16 matrix cores with exact 3 x bf16 operand splits -- unless the atoms are so heavy (C*Ay*Ax > 576,
-    # config 5) that the transforms are cheaper than C*Ay*Ax multiply-adds per activation: then it stays on the FFT family
-    heavy = C * A[0] * A[1] > 576
-    assert be.last_path == ('fft' if heavy else 'split')
+    assert be.last_path == 'split'          # H gradient: bf16 matrix cores, exact 3 x bf16 operand splits
     nW, pW = be.reconstruction_gradient_W(V, W, H)
     assert be.last_path == 'fft'
     Hf = H.clone()
     be.fused_update_H(V, W, Hf, slice(None), sparsity=0.05, eps=1e-9)
-    assert be.last_path == ('fft' if heavy else 'split')
+    assert be.last_path == 'split'
     Wf = W.clone()
     be.fused_update_W(V, Wf, Hf, slice(None), eps=1e-9)
     for name, got, ref in zip('R nH pH nW pW Hf Wf'.split(), (R, nH, pH, nW, pW, Hf, Wf), want):
-        # (FFT-family H update: see test_fft_family_at_baseline_sizes for the bound on the updated H)
-        assert relmax(be.to_ndarray(got), ref) < (2e-3 if heavy and name == 'Hf' else 2e-5), name
+        assert relmax(be.to_ndarray(got), ref) < 2e-5, name
 
 
 @pytest.mark.parametrize('C,D,M,A', BASELINE_SHAPES, ids=['config2', 'config3', 'config4', 'config5'])

@@ -90,11 +90,7 @@ def test_cyclic_mu_f32_at_shard_geometry(C, D, M, A):
     dW, dH = relmax(nmf.W, ref.W), relmax(nmf.H, ref.H)
     gap = abs(nmf._energy_function() - ref.energy()) / ref.energy()
     print(f'cyclic {C}x{D} m{M} a{A}: dW={dW:.2e} dH={dH:.2e} gap={gap:.2e}')
-    # The default dispatch keeps the H half step in the FFT family when C*Ay*Ax > 576 (config-5 geometry): float32
-    # transforms leave rounding noise of ~1e-4 of max|H| in the entries of H (the products are exact only in the direct
-    # families); W and the energy, the BASELINE.json parity quantities, keep the 1e-5 bar.
-    h_bound = 5e-3 if C * A[0] * A[1] > 576 else 1e-5
-    assert dW < 1e-5 and dH < h_bound and gap < 1e-5, (dW, dH, gap)
+    assert dW < 1e-5 and dH < 1e-5 and gap < 1e-5, (dW, dH, gap)
 
 
 # ---------------------------------------------------------------------------------------------------------------

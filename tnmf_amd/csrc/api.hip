@@ -98,16 +98,6 @@ bool use_fft_hybrid(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
     return (size_t)g.N * g.M * g.Hy * g.Hx >= ((size_t)1 << 19);
 }
 
-// AUTO: the H half step stays in the FFT family when the direct kernels' work per activation, C * Ay * Ax multiply-adds,
-// outweighs the transforms.  Measured on MI355X (hybrid = split kernel + re-transforming H vs. pure FFT, ms per
-// iteration): C*Ay*Ax = 144 (config 3) 5.6 vs 7.9; 432 (config 4) 11.3 vs 12.6; 768 (config 5 shard) 53.7 vs 47.3 --
-// the lines cross near 580.
-bool fft_takes_H(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
-    if (ctx->path != TNMF_PATH_AUTO || !use_fft_hybrid(ctx, g, dtype)) return false;
-    if (g.Dy == 1 || g.Ay == 1) return false;   // 1-D: the family has no H half step there
-    return (long)g.C * g.Ay * g.Ax > 576;
-}
-
 // H gradient on the bf16 matrix cores with exact 3 x bf16 operand splits: forced by TNMF_PATH_SPLIT, default under AUTO
 // and HYBRID (tnmf_hip_ctx_set_split), never under MFMA (the exact-f32 family), GENERIC or FFT.
 bool use_split(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
@@ -163,11 +153,11 @@ int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, co
 int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *Hio,
               void *neg, void *pos, bool fused, double reg, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
-    if (ctx->path == TNMF_PATH_FFT || fft_takes_H(ctx, g, dtype)) {
-        const int rc =
-            fused ? fft_update_H(ctx, g, dtype, V, R, W, Hio, reg, s) : fft_grad_H(ctx, g, dtype, V, R, W, neg, pos, s);
-        if (!(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
-    }
+    // (AUTO never takes the FFT family here, although it is the faster one for heavy atoms -- 46 vs 53 ms per iteration
+    // at config 5's shard, C*Ay*Ax = 768: its float32 transform noise leaves 4e-4 of max|H| in the activations, and the
+    // parity bar of the default path is 1e-5 on W AND H.  path = FFT is the opt-in.)
+    if (ctx->path == TNMF_PATH_FFT)
+        return fused ? fft_update_H(ctx, g, dtype, V, R, W, Hio, reg, s) : fft_grad_H(ctx, g, dtype, V, R, W, neg, pos, s);
     if (fused) fft_invalidate_H(ctx);   // the direct kernels are about to change H: cached row spectra are stale
     if (use_split(ctx, g, dtype)) {
         const int rc = split_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio,
@@ -230,7 +220,7 @@ int tnmf_hip_ctx_h_row_stride(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int 
     // padded rows pay where the split kernel reads and writes H in 32-pixel tiles and every other reader of H is the
     // FFT family's row transform; a whole number of 128-byte lines per row
     const bool hybrid = ctx->path == TNMF_PATH_AUTO || ctx->path == TNMF_PATH_HYBRID;
-    if (hybrid && g.N > 0 && use_fft_hybrid(ctx, g, dtype) && use_split(ctx, g, dtype) && !fft_takes_H(ctx, g, dtype))
+    if (hybrid && g.N > 0 && use_fft_hybrid(ctx, g, dtype) && use_split(ctx, g, dtype))
         *stride_out = (int)align_up((size_t)g.Hx, 32);
     return TNMF_OK;
 }
@@ -304,7 +294,7 @@ int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom) {
     (void)s;
     if (g.N > 0 && ctx->path == TNMF_PATH_FFT) CHECK(fft_reserve(ctx, g, dtype, true));
     if (g.N > 0 && use_fft_hybrid(ctx, g, dtype)) {
-        const int rc = fft_reserve(ctx, g, dtype, fft_takes_H(ctx, g, dtype));
+        const int rc = fft_reserve(ctx, g, dtype, false);
         if (rc != TNMF_OK && !(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
     }
     return ensure_scratch(ctx, plan_scratch(ctx, g, dtype).total);

@@ -5,7 +5,7 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("it/s %.2f  ms/step %.3f  path %s" % (d["value"], d["ms_per_step"], d["config"]["kernel_path"]))
 for k, v in d["kernels"].items():
     print("  %-12s %-6s avg %.3f ms x %d" % (k, v.get("family"), v["avg_ms"], v["launches"]))
-for k in ("exact_f32_variant", "hybrid_split_variant", "direct_variant", "fft_variant"):
+for k in ("exact_f32_variant", "direct_variant", "fft_variant"):
     if k in d and "value" in d[k]:
         print("  %s: %.2f it/s  %s" % (k, d[k]["value"], {a: round(b, 3) for a, b in d[k]["kernels_ms"].items()}))
 if "parity" in d:
