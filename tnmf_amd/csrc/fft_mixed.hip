@@ -87,6 +87,65 @@ __global__ __launch_bounds__(kMixCols *STRIPS, 2) void k_mix_reconstruct(const c
 #pragma unroll
         for (int r = 0; r < S + AY - 1; ++r) t[r] = ld(rs, lane_t, r * rowb);
     }
+    if constexpr (CG == 1) {
+        // One channel: the AY rows of W spectra of an atom are the same for all STRIPS strips of the workgroup.  Loaded
+        // per thread they were 12 of the 39 memory instructions of an atom step and -- although they hit in L2 -- a
+        // fifth of the kernel (measured with constants in their place: 0.69 -> 0.575 ms).  They are staged through LDS in
+        // chunks of MC atoms: 16-byte loads one chunk ahead (in flight under the atoms of the current chunk), one
+        // barrier per chunk, and an atom step reads its rows with AY ds_read_b64 (all strips of a wave read the same
+        // addresses: a broadcast).
+        constexpr int MC = 8, NT = kMixCols * STRIPS, ROWS = MC * AY, PIECES = ROWS * (kMixCols / 2);
+        constexpr int NPP = (PIECES + NT - 1) / NT;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        __shared__ __align__(16) cplx<T> wl[2][ROWS * kMixCols];
+        const cplx<T> *wsrc = WT + blockIdx.x * kMixCols;   // (KXP is a multiple of 16 entries: whole 128-byte segments)
+        const int wrows = M * AY;
+        f4v pre[NPP];
+        auto wfetch = [&](int chunk) {
+#pragma unroll
+            for (int k = 0; k < NPP; ++k) {
+                const int p = threadIdx.x + k * NT, row = min(chunk * ROWS + (p >> 3), wrows - 1);
+                pre[k] = *reinterpret_cast<const f4v *>(wsrc + (long)row * KXP + 2 * (p & 7));
+            }
+        };
+        auto wpark = [&](int buf) {
+#pragma unroll
+            for (int k = 0; k < NPP; ++k) {
+                const int p = threadIdx.x + k * NT;
+                if (p < PIECES) *reinterpret_cast<f4v *>(&wl[buf][(p >> 3) * kMixCols + 2 * (p & 7)]) = pre[k];
+            }
+        };
+        wfetch(0);
+        wpark(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int m0 = 0, ch = 0; m0 < M; m0 += MC, ++ch) {
+            const int buf = ch & 1;
+            const bool more = m0 + MC < M;
+            if (more) wfetch(ch + 1);
+#pragma unroll 1
+            for (int mi = 0; mi < MC; ++mi) {
+                const int m = m0 + mi;
+                if (m >= M) break;
+                cplx<T> w[AY];
+#pragma unroll
+                for (int a = 0; a < AY; ++a) w[a] = wl[buf][(mi * AY + (AY - 1 - a)) * kMixCols + col];
+                {
+                    const __amdgpu_buffer_rsrc_t rs = plane(min(m + 1, M - 1));
+#pragma unroll
+                    for (int r = 0; r < S + AY - 1; ++r) tn[r] = ld(rs, lane_t, r * rowb);
+                }
+#pragma unroll
+                for (int a = 0; a < AY; ++a)
+#pragma unroll
+                    for (int y = 0; y < S; ++y) cfma(acc[0][y], t[y + a], w[a]);
+#pragma unroll
+                for (int r = 0; r < S + AY - 1; ++r) t[r] = tn[r];
+            }
+            if (more) wpark(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
 #pragma unroll 1
     for (int m = 0; m < M; ++m) {
         cplx<T> w[CG][AY];
@@ -109,6 +168,7 @@ __global__ __launch_bounds__(kMixCols *STRIPS, 2) void k_mix_reconstruct(const c
                 for (int y = 0; y < S; ++y) cfma(acc[c][y], t[y + a], w[c][a]);
 #pragma unroll
         for (int r = 0; r < S + AY - 1; ++r) t[r] = tn[r];
+    }
     }
     if (kx >= KX) return;
 #pragma unroll
