@@ -134,9 +134,9 @@ int main() {
         run<8>(src, n4, out, bpc);
     }
     for (int bpc : {4, 8}) {
-        run8<4, 0>(src, n4, out, bpc);
-        run8<16, 0>(src, n4, out, bpc);
-        run8<27, 0>(src, n4, out, bpc);
+        run8<4, 2>(src, n4, out, bpc);
+        run8<16, 2>(src, n4, out, bpc);
+        run8<27, 2>(src, n4, out, bpc);
         run8<27, 7>(src, n4, out, bpc);
         run8<27, 14>(src, n4, out, bpc);
     }
