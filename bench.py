@@ -178,8 +178,8 @@ def cpu_baseline(cfg, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument('--samples', type=int, default=None, help='override samples per GPU (debug)')
     ap.add_argument('--path', default='auto', choices=['auto', 'generic', 'mfma', 'split', 'fft', 'hybrid'])
