@@ -355,3 +355,41 @@ def test_front_end_runs_on_row_padded_activations():
     gap = abs(nmf._energy_function() - ref.energy()) / ref.energy()
     print(f'padded rows: dW={dW:.2e} dH={dH:.2e} gap={gap:.2e}')
     assert dW < 1e-5 and dH < 1e-5 and gap < 1e-5, (dW, dH, gap)
+
+
+@pytest.mark.parametrize('kw', [dict(inhibition_strength=0.1, cross_atom_inhibition_strength=0.05, sparsity_H=0.02),
+                                dict(algorithm='asg', batch_size=2, n_epochs=2),
+                                dict(keep='W')],
+                         ids=['inhibition', 'stochastic_minibatches', 'refit_keeping_W'])
+def test_front_end_branches_on_row_padded_activations(kw):
+    """The front-end branches that touch H outside the fused kernels -- inhibition (separable convolutions of H, sums
+    over the atom axis, `g - H[s]`), a stochastic mini-batch schedule (H slices, accumulators) and a second fit that
+    keeps W -- on the padded view, against the float64 oracle."""
+    oracle_threads()
+    N, C, D, M, A = 4, 1, (96, 80), 32, (12, 12)
+    V = planted_V(N, C, D, M, A, seed=9)
+    hip_kw, ref_kw = dict(kw), dict(kw)
+    if kw.get('algorithm') == 'asg':
+        hip_kw['algorithm'] = MiniBatchAlgorithm.ASG_MU
+        ref_kw['algorithm'] = orc.MiniBatchAlgorithm.ASG_MU
+    else:
+        hip_kw.setdefault('n_iterations', 3)
+        ref_kw.setdefault('n_iterations', 3)
+    refit = hip_kw.pop('keep', None) is not None
+    ref_kw.pop('keep', None)
+    cb = lambda *_: True  # noqa: E731
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=M, atom_shape=A, backend='hip')
+    nmf.fit(V, progress_callback=cb, **hip_kw)
+    if refit:
+        nmf.fit(V, keep_W=True, progress_callback=cb, **hip_kw)
+    assert not nmf._H.is_contiguous() and nmf._H.stride(2) == 96
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c')
+    ref.fit(V.astype(np.float64), **ref_kw)
+    if refit:
+        ref.fit(V.astype(np.float64), keep_W=True, **ref_kw)
+    dW, dH = relmax(nmf.W, ref.W), relmax(nmf.H, ref.H)
+    gap = abs(nmf._energy_function() - ref.energy()) / ref.energy()
+    print(f'{kw}: dW={dW:.2e} dH={dH:.2e} gap={gap:.2e}')
+    assert dW < 1e-5 and dH < 2e-5 and gap < 1e-5, (dW, dH, gap)
