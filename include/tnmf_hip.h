@@ -63,7 +63,7 @@ typedef struct {
 /* Kernel family selection (tnmf_hip_ctx_set_path): AUTO picks the MFMA kernels where the shape allows and, for float32
  * problems with at least 2^19 activation entries, the HYBRID dispatch described below.  FFT is the
  * frequency-domain formulation (the algorithm of the reference's default backend, tnmf/backends/NumPy_FFT.py:16-40):
- * float32 2-D problems with shift shapes up to 576, float64 up to 144. */
+ * float32 2-D problems with shift shapes up to 576, float64 up to 288. */
 enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_FFT = 3, TNMF_PATH_HYBRID = 4,
        TNMF_PATH_SPLIT = 5 };
 /* HYBRID: reconstruct and the W gradient on the FFT family (their float32 transform error is benign: R has no small

@@ -332,8 +332,8 @@ FFT_SHAPES = [
     (5, 5, (24, 40), 3, (3, 7), 'df'),         # 32, 48; more channels than one register group
     (2, 1, (40, 50), 4, (20, 6), 'df'),        # 64, 64; atoms taller than the mixed contractions take (16 rows)
     (2, 1, (128, 128), 16, (9, 9), 'df'),      # 144, 144
-    (2, 3, (100, 170), 8, (12, 12), 'f'),      # 144, 192
-    (1, 3, (256, 200), 8, (12, 12), 'f'),      # 288, 288
+    (2, 3, (100, 170), 8, (12, 12), 'df'),     # 144, 192
+    (1, 3, (256, 200), 8, (12, 12), 'df'),     # 288, 288
     (1, 1, (300, 500), 4, (16, 16), 'f'),      # 384, 576
 ]
 
@@ -343,7 +343,7 @@ FFT_SHAPES = [
 def test_fft_family_against_oracle(shape, dtype, tol):
     N, C, D, M, A, kinds = shape
     if ('d' if dtype == np.float64 else 'f') not in kinds:
-        pytest.skip('float64 transforms are instantiated up to length 144')
+        pytest.skip('float64 transforms are instantiated up to length 288')
     rng = np.random.default_rng(N * 1000 + M)
     V = rng.random((N, C) + D)
     Wn = rng.random((M, C) + A)

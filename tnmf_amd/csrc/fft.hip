@@ -21,7 +21,7 @@ constexpr int kMixMaxGroups = 128;   // partial-sum slots of the mixed W-gradien
 
 int pick_len(int h, int dtype) {
     for (int L : kLens)
-        if (L >= h && (dtype == 0 || L <= 144)) return L;
+        if (L >= h && (dtype == 0 || L <= 288)) return L;
     return 0;
 }
 

@@ -704,7 +704,9 @@ int set_lds_limit(K kernel, size_t bytes) {
 template <typename T, int L>
 int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
     using Cfg = LenCfg<L>;
-    constexpr int NB = Cfg::row_pairs, NTR = Cfg::row_threads, NTC = Cfg::col_threads;
+    // (float64 tiles are twice the bytes: half the row pairs per tile for the longer transforms)
+    constexpr int NB = (sizeof(T) == 8 && L > 144) ? Cfg::row_pairs / 2 : Cfg::row_pairs;
+    constexpr int NTR = Cfg::row_threads, NTC = Cfg::col_threads;
     constexpr size_t row_tile = (size_t)L * (NB + 1) * sizeof(cplx<T>), tw_bytes = (size_t)L * sizeof(cplx<T>);
     constexpr size_t col_lds = (size_t)L * (LenCfg<L>::col_tile + 1) * sizeof(cplx<T>) + tw_bytes;
     constexpr size_t wide_lds = (size_t)L * 17 * sizeof(cplx<T>) + tw_bytes;
@@ -725,7 +727,7 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
         case kFftRowsInv: TNMF_FFT_LAUNCH((k_fft_rows_inv<T, L, NB, NTR, 0>), rgrid, NTR, row_tile + tw_bytes);
         case kFftRowsInv2: TNMF_FFT_LAUNCH((k_fft_rows_inv<T, L, NB, NTR, 1>), rgrid, NTR, 2 * row_tile + tw_bytes);
         case kFftRowsMu: {
-            constexpr int NBM = Cfg::mu_pairs;
+            constexpr int NBM = (sizeof(T) == 8 && L > 144) ? Cfg::mu_pairs / 2 : Cfg::mu_pairs;
             const dim3 mgrid((unsigned)cdiv(a->rows, 2 * NBM), (unsigned)a->planes);
             constexpr int NTM = Cfg::mu_threads;
             constexpr size_t stash = L > NTM ? (size_t)(L - NTM) * 2 * NBM * sizeof(T) : 0;

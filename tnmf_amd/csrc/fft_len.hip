@@ -1,5 +1,5 @@
 // fft_len.hip -- one object per transform length: compiled with -DTNMF_FFT_L=<L> (see Makefile), it instantiates the
-// kernels of fft_kernels.h for that length (float always, double for the lengths up to 144 that the float64 parity tests use).
+// kernels of fft_kernels.h for that length (float always, double for the lengths up to 288: the float64 parity tests up to the BASELINE config-3 geometry).
 #include "fft_kernels.h"
 
 #ifndef TNMF_FFT_L
@@ -11,6 +11,6 @@
 int TNMF_CAT(fft_run_, TNMF_FFT_L)(int op, int dtype, const FftArgs *a, hipStream_t s) {
     constexpr int L = TNMF_FFT_L;
     if (dtype == 0) return fft_run_typed<float, L>(op, a, s);
-    if constexpr (L <= 144) return fft_run_typed<double, L>(op, a, s);
+    if constexpr (L <= 288) return fft_run_typed<double, L>(op, a, s);
     return TNMF_E_UNSUPPORTED;
 }
