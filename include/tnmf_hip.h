@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TNMF_HIP_ABI_VERSION 4
+#define TNMF_HIP_ABI_VERSION 5
 
 enum {
     TNMF_OK = 0,
@@ -90,7 +90,9 @@ const char *tnmf_hip_strerror(int code);
 /* One context per device: caches device properties and owns the scratch (R, split-K partials). */
 int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out);
 int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx);
-/* Pre-size the scratch for `geom` so that later calls allocate nothing (graph-capture safe). */
+/* Pre-size the scratch for `geom` so that later calls allocate nothing (graph-capture safe).  Also forgets a workspace
+ * size the FFT family was refused earlier (such a size is otherwise not attempted again: under TNMF_PATH_AUTO the
+ * direct kernels take over silently), so call it again after freeing device memory. */
 int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom);
 int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path);
 /* Name of the kernel family the last primitive call on this ctx dispatched to ("generic", "mfma", "split", "fft"). */
@@ -102,6 +104,19 @@ const char *tnmf_hip_ctx_last_path(const tnmf_hip_ctx *ctx);
  * writing either by any other means. */
 int tnmf_hip_ctx_set_cache(tnmf_hip_ctx *ctx, int enable);
 int tnmf_hip_ctx_invalidate(tnmf_hip_ctx *ctx);
+/* The resident problem of a fit: geom->N samples of activations at H (row stride geom->h_row_stride) and of samples at V
+ * (may be NULL).  With the cache enabled, a later call whose H pointer is a whole number of samples into this H -- a
+ * mini-batch slice, the way the reference's backends receive `H[s]` (tnmf/backends/NumPy.py:77-80,101) -- works on the
+ * matching sample range of ONE cache with per-sample validity: a Cyclic-MU epoch transforms every batch once, like a
+ * full-batch iteration (the reference's counterpart: per-slice caches, tnmf/backends/NumPy_CachingFFT.py:143-158).
+ * Such slices also follow the kernel-family choice of the resident problem (TNMF_PATH_AUTO decides by its size, not
+ * the slice's), so row-padded activations never meet a family that wants them C-contiguous.  Without a binding the cache
+ * follows the operands of the last call.  H == NULL or geom == NULL drops the binding.  The binding holds no reference:
+ * the caller re-binds (or invalidates) when the buffers are replaced. */
+int tnmf_hip_ctx_bind(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *H, const void *V);
+/* Observability of the cache: out[0] / out[1] = row-transform passes over activations that ran / were skipped because
+ * the cache held every sample of the call, out[2] / out[3] the same for the samples V (counted since ctx creation). */
+int tnmf_hip_ctx_cache_counters(const tnmf_hip_ctx *ctx, unsigned long long out[4]);
 
 /* ---- primitives: API-parity path --------------------------------------------------------------------------- */
 

@@ -217,6 +217,71 @@ def test_foreign_write_to_H_between_fused_calls(path):
     assert relmax(be.to_ndarray(got), Wo) < 4e-5, f'same address: {Hnew.data_ptr() == ptr}'
 
 
+@pytest.mark.parametrize('path', ['hybrid', 'fft'])
+def test_minibatch_slices_share_one_spectrum_cache(path):
+    """Cyclic-MU over mini-batch slices of the backend's own H (reference TransformInvariantNMF.py:457-465; per-slice
+    caches: NumPy_CachingFFT.py:143-158): every batch is row-transformed ONCE per epoch -- like a full-batch iteration --
+    and a torch-side write that hits one batch only is seen (the whole cache is dropped: conservative)."""
+    N, C, D, M, A, B = 6, 1, (40, 48), 6, (7, 7), 2
+    rng = np.random.default_rng(19)
+    V = rng.random((N, C) + D).astype(np.float32)
+    be = HIP_Backend(path=path)
+    np.random.seed(3)
+    W, H = be.initialize(V, A, M, None, (-2, -1))
+    Wn, Hn = be.to_ndarray(W).astype(np.float64), be.to_ndarray(H).astype(np.float64)
+    Vn = V.astype(np.float64)
+    batches = [slice(lo, lo + B) for lo in range(0, N, B)]
+    tol_H = 2e-3 if path == 'fft' else 4e-5    # (pure FFT H update: float32 transform noise, DESIGN.md 4b)
+
+    def epoch():
+        total = None
+        for b in batches:
+            be.fused_update_H(V, W, H, b, sparsity=0., eps=1e-9)
+            part = be.local_gradient_W(V, W, H, b)
+            total = part if total is None else total.add_(part)
+        be.apply_W(W, total, eps=1e-9)
+
+    def oracle_epoch(Wn, Hn):
+        neg = pos = 0.
+        for b in batches:
+            on, op = orc.gradient_H(Vn, Wn, Hn, b, 'c')
+            Hn[b] = Hn[b] * on / (op + 1e-9)
+            gn, gp = orc.gradient_W(Vn, Wn, Hn, b, 'c')
+            neg, pos = neg + gn, pos + gp
+        Wn = Wn * neg / (pos + 1e-9)
+        return Wn / Wn.sum(axis=(-2, -1), keepdims=True), Hn
+
+    c0 = be.cache_counters
+    epoch()
+    Wn, Hn = oracle_epoch(Wn, Hn)
+    c1 = be.cache_counters
+    epoch()
+    Wn, Hn = oracle_epoch(Wn, Hn)
+    c2 = be.cache_counters
+    assert relmax(be.to_ndarray(W), Wn) < 4e-5 and relmax(be.to_ndarray(H), Hn) < tol_H
+    per_epoch = c2['h_runs'] - c1['h_runs']
+    # hybrid: the direct H update changes H, so each batch is transformed once (for the W half step) and the next
+    # epoch's reconstruct of the same batch finds it cached; pure FFT: the fused update leaves the new spectra behind
+    assert per_epoch == (len(batches) if path == 'hybrid' else 0), (c0, c1, c2)
+    assert c2['h_hits'] - c1['h_hits'] >= len(batches)
+    assert c2['v_runs'] == c1['v_runs'], 'the samples never change: their spectra are computed once'
+    # a torch-side write that hits ONE batch only
+    H[2:4].mul_(0.5)
+    Hn[2:4] *= 0.5
+    epoch()
+    Wn, Hn = oracle_epoch(Wn, Hn)
+    assert relmax(be.to_ndarray(W), Wn) < 4e-5 and relmax(be.to_ndarray(H), Hn) < tol_H
+    # ... and a write through a slice view of one sample, between the two half steps of a batch
+    be.fused_update_H(V, W, H, batches[1], sparsity=0., eps=1e-9)
+    on, op = orc.gradient_H(Vn, Wn, Hn, batches[1], 'c')
+    Hn[batches[1]] = Hn[batches[1]] * on / (op + 1e-9)
+    H[3].add_(0.125)
+    Hn[3] += 0.125
+    got = be.local_gradient_W(V, W, H, batches[1])
+    gn, gp = orc.gradient_W(Vn, Wn, Hn, batches[1], 'c')
+    assert relmax(got[0].cpu().numpy(), gn) < 4e-5 and relmax(got[1].cpu().numpy(), gp) < 4e-5
+
+
 def test_reflect_mode_rejects_a_pad_as_long_as_the_row():
     """torch's reflect pad needs pad < size (_PyTorchBackend.py:42-52): atom 5 on 4 shifts must fail, not read past H."""
     be = HIP_Backend(reconstruction_mode='reflect')

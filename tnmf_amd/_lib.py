@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libtnmf_hip.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/tnmf_hip.h declares
 EXPORTS = (
@@ -20,7 +20,8 @@ EXPORTS = (
     'tnmf_hip_grad_H', 'tnmf_hip_grad_W', 'tnmf_hip_mu_update', 'tnmf_hip_normalize_W', 'tnmf_hip_energy',
     'tnmf_hip_convolve_multi_1d', 'tnmf_hip_update_H', 'tnmf_hip_grad_W_fused', 'tnmf_hip_apply_W',
     'tnmf_hip_pad_H', 'tnmf_hip_fold_H', 'tnmf_hip_ctx_set_cache', 'tnmf_hip_ctx_invalidate',
-    'tnmf_hip_ctx_set_split', 'tnmf_hip_ctx_h_row_stride',
+    'tnmf_hip_ctx_set_split', 'tnmf_hip_ctx_h_row_stride', 'tnmf_hip_ctx_bind',
+    'tnmf_hip_ctx_cache_counters',
 )
 
 MODES = {'valid': 0, 'full': 1, 'circular': 2, 'reflect': 3}
@@ -73,6 +74,8 @@ def load() -> ctypes.CDLL:
     lib.tnmf_hip_ctx_set_split.argtypes = [vp, ci]
     lib.tnmf_hip_ctx_h_row_stride.argtypes = [vp, gp, ctypes.POINTER(ci)]
     lib.tnmf_hip_ctx_invalidate.argtypes = [vp]
+    lib.tnmf_hip_ctx_bind.argtypes = [vp, gp, vp, vp]
+    lib.tnmf_hip_ctx_cache_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong * 4)]
     lib.tnmf_hip_ctx_last_path.restype = ctypes.c_char_p
     lib.tnmf_hip_ctx_last_path.argtypes = [vp]
     lib.tnmf_hip_reconstruct.argtypes = [vp, gp, vp, vp, vp, vp]

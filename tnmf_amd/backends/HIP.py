@@ -143,21 +143,29 @@ class HIP_Backend(Backend):
     def last_path(self) -> str:
         return self._lib.tnmf_hip_ctx_last_path(self._ctx).decode()
 
+    @property
+    def cache_counters(self) -> dict:
+        """Row-transform passes of the FFT family over H / V that ran, and that the spectrum cache made unnecessary."""
+        out = (ctypes.c_ulonglong * 4)()
+        _lib.check(self._lib.tnmf_hip_ctx_cache_counters(self._ctx, ctypes.byref(out)), 'tnmf_hip_ctx_cache_counters')
+        return dict(h_runs=int(out[0]), h_hits=int(out[1]), v_runs=int(out[2]), v_hits=int(out[3]))
+
     def _foreign_H(self) -> None:
         """H of the coming call may have been written by someone else: drop cached spectra (FFT family)."""
         self._lib.tnmf_hip_ctx_invalidate(self._ctx)
         self._cached_H = None
 
-    # The FFT family may keep the row spectra of the activations it transformed or updated last
-    # (tnmf_hip_ctx_set_cache); the library can only key that cache on the raw pointer.  Validity is therefore owned
-    # HERE: after each fused call the identity of the tensor (weak reference to its base), its pointer, shape and
-    # torch's version counter are recorded; a fused call whose H does not match -- another tensor at the same address,
-    # or the same tensor written by any torch operation in between (which bumps the counter; the library's own writes
-    # through the raw pointer do not) -- invalidates first.
+    # The FFT family keeps the row spectra of the activations it transformed or updated (tnmf_hip_ctx_set_cache), per
+    # sample of the resident H it was told about (tnmf_hip_ctx_bind in initialize(): mini-batch slices H[s] share one
+    # cache, the way the reference's caching backend keeps one cache per slice, NumPy_CachingFFT.py:143-158).  The library
+    # can only key that cache on raw pointers; validity is therefore owned HERE: after each fused call the identity of
+    # the storage (weak reference to the base tensor of the slice) and torch's version counter are recorded; a fused call
+    # on other storage, or on the same storage written by any torch operation in between (which bumps the counter; the
+    # library's own writes through the raw pointer do not) -- whichever samples that write hit -- invalidates first.
     @staticmethod
     def _h_key(Hs: torch.Tensor):
         base = Hs._base if Hs._base is not None else Hs
-        return base, (Hs.data_ptr(), tuple(Hs.shape), base._version)
+        return base, (base.data_ptr(), tuple(base.shape), base._version)
 
     def _validate_H_cache(self, Hs: torch.Tensor) -> None:
         c = self._cached_H
@@ -342,6 +350,11 @@ class HIP_Backend(Backend):
             self._R_scratch = torch.empty_like(self._V_dev)
             self._negpos = torch.empty((2, n_atoms, self.n_channels) + self.atom_shape, dtype=self._torch_dtype,
                                        device=self._device)
+            # the resident problem of this fit: slices H[s] / V[s] of it share the library's spectrum cache
+            bound = self._mode == 0 and n1 > n0
+            _lib.check(self._lib.tnmf_hip_ctx_bind(
+                self._ctx, ctypes.byref(self._geom(n1 - n0, n_atoms, max(ld.value, 0))) if bound else None,
+                _ptr(H) if bound else None, _ptr(self._V_dev) if bound else None), 'tnmf_hip_ctx_bind')
             _lib.check(self._lib.tnmf_hip_ctx_reserve(self._ctx, ctypes.byref(self._geom(n1 - n0, n_atoms))),
                        'tnmf_hip_ctx_reserve')
         return W, H

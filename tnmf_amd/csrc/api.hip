@@ -67,17 +67,26 @@ Scratch plan_scratch(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
 
 int ensure_scratch(tnmf_hip_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return TNMF_OK;
+    // the larger buffer is allocated BEFORE the current one is released, so a failure leaves the working one in place;
+    // when both do not fit side by side the old order (release, then allocate) is tried once
+    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    void *bigger = nullptr;
+    if (hipMalloc(&bigger, want) != hipSuccess) {
+        (void)hipGetLastError();
+        bigger = nullptr;
+        if (!ctx->ws) return TNMF_E_WORKSPACE;
+    }
     if (ctx->ws) {
         TNMF_HIP_TRY(hipDeviceSynchronize());
         TNMF_HIP_TRY(hipFree(ctx->ws));
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
     }
-    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
-    if (hipMalloc(&ctx->ws, want) != hipSuccess) {
+    if (!bigger && hipMalloc(&bigger, want) != hipSuccess) {
         (void)hipGetLastError();
         return TNMF_E_WORKSPACE;
     }
+    ctx->ws = bigger;
     ctx->ws_bytes = want;
     return TNMF_OK;
 }
@@ -90,12 +99,15 @@ enum Prim { kReconstruct, kCorrW, kCorrH };
 // covers the shape; chosen by TNMF_PATH_AUTO for float32 problems that are not tiny (the family costs ~20 launches per iteration).
 // Measured: W, H and the energy stay as close to the float64 oracle as with the direct kernels alone,
 // because the H gradient -- the only place where float32 transform error matters -- stays on the direct kernels.
-bool use_fft_hybrid(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
+// A mini-batch slice of the bound activations (tnmf_hip_ctx_bind) follows the family of the resident problem: its H has
+// the resident problem's row stride, and its spectra live in the resident problem's cache.
+bool use_fft_hybrid(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H = nullptr) {
     if (ctx->path == TNMF_PATH_HYBRID) return fft_has(g, dtype);
     if (ctx->path != TNMF_PATH_AUTO || dtype != 0 || !fft_has(g, dtype)) return false;
     // measured crossover against the direct kernels at 128x128 samples, 16 atoms: one sample (2^18 entries) is a tie,
     // two are 20 % ahead, 64 samples (config 2) 1.9x
-    return (size_t)g.N * g.M * g.Hy * g.Hx >= ((size_t)1 << 19);
+    const int n = H ? fft_bound_samples(ctx, g, dtype, H) : g.N;
+    return (size_t)n * g.M * g.Hy * g.Hx >= ((size_t)1 << 19);
 }
 
 // H gradient on the bf16 matrix cores with exact 3 x bf16 operand splits: forced by TNMF_PATH_SPLIT, default under AUTO
@@ -135,7 +147,7 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
 int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
     // the FFT family serves non-negative factorisations: outputs that are non-negative by construction are clamped
-    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype)) {
+    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype, H)) {
         const int rc = fft_reconstruct(ctx, g, dtype, W, H, R, true, s);
         // AUTO only chose the family for speed: when its workspace does not fit, the direct kernels still do the job
         if (!(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
@@ -158,7 +170,7 @@ int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const v
     // parity bar of the default path is 1e-5 on W AND H.  path = FFT is the opt-in.)
     if (ctx->path == TNMF_PATH_FFT)
         return fused ? fft_update_H(ctx, g, dtype, V, R, W, Hio, reg, s) : fft_grad_H(ctx, g, dtype, V, R, W, neg, pos, s);
-    if (fused) fft_invalidate_H(ctx);   // the direct kernels are about to change H: cached row spectra are stale
+    if (fused) fft_invalidate_H(ctx, g, dtype, Hio);   // the direct kernels are about to change H: its cached spectra are stale
     if (use_split(ctx, g, dtype)) {
         const int rc = split_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio,
                                     (float *)neg, (float *)pos, fused, (float)reg, s);
@@ -186,7 +198,7 @@ int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, con
         TNMF_HIP_TRY(hipMemsetAsync(pos, 0, (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype), s));
         return TNMF_OK;
     }
-    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype)) {
+    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype, H)) {
         const int rc = fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, true, s);
         if (!(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
     }
@@ -316,7 +328,29 @@ int tnmf_hip_ctx_set_split(tnmf_hip_ctx *ctx, int enable) {
 int tnmf_hip_ctx_set_cache(tnmf_hip_ctx *ctx, int enable) {
     if (!ctx) return TNMF_E_NULL;
     ctx->fft.cache_enabled = enable != 0;
-    ctx->fft.T_valid = false;
+    fft_invalidate(ctx);
+    return TNMF_OK;
+}
+
+int tnmf_hip_ctx_bind(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *H, const void *V) {
+    if (!ctx) return TNMF_E_NULL;
+    if (!geom || !H) {
+        fft_unbind(ctx);
+        return TNMF_OK;
+    }
+    Geo g;
+    const int rc = to_geo(geom, &g);
+    if (rc != TNMF_OK) return rc;
+    fft_bind(ctx, g, geom->dtype, H, V);
+    return TNMF_OK;
+}
+
+int tnmf_hip_ctx_cache_counters(const tnmf_hip_ctx *ctx, unsigned long long out[4]) {
+    if (!ctx || !out) return TNMF_E_NULL;
+    out[0] = ctx->fft.h_runs;
+    out[1] = ctx->fft.h_hits;
+    out[2] = ctx->fft.v_runs;
+    out[3] = ctx->fft.v_hits;
     return TNMF_OK;
 }
 

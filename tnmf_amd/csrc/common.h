@@ -16,23 +16,34 @@ struct Geo {
     int Hs;      // row stride of H in elements (>= Hx; == Hx: C-contiguous)
 };
 
-// state of the FFT kernel family (fft.hip): its own workspace and the cache of the row spectra of H
+// state of the FFT kernel family (fft.hip): its own workspace and the cache of the spectra of H and V.
+//
+// The workspace mirrors ONE resident problem -- the "binding": base pointers of the activations H and the samples V of
+// `geo.N` samples (tnmf_hip_ctx_bind, or implicitly the operands of the last call).  A call whose H pointer is a whole
+// number of samples into the bound H (a mini-batch slice) works on the matching sample range of every per-sample array
+// of the workspace, and validity is kept PER SAMPLE: a Cyclic-MU epoch transforms every batch once, exactly like a
+// full-batch iteration (the reference's per-slice caches: NumPy_CachingFFT.py:143-158).
+#include <vector>
 struct FftState {
-    void *ws;
-    size_t ws_bytes;
-    size_t failed_bytes;     // smallest workspace request that hipMalloc has refused (0: none); sticky until release
-    bool cache_enabled;      // the caller vouches that H and V only change through this library or are announced
-                             // with tnmf_hip_ctx_invalidate (tnmf_hip_ctx_set_cache)
-    bool T_valid;            // the workspace holds the row spectra of T_owner for T_geo / T_dtype
-    bool SH_valid;           // ... and their column transforms (full spectra of H) as well
-    const void *T_owner;
-    Geo T_geo;
-    int T_dtype;
-    bool V_valid;            // ... and the row spectra of the samples V_owner (same geometry rules)
-    bool SV_valid;           // ... and their full spectra as well
-    const void *V_owner;
-    Geo V_geo;
-    int V_dtype;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    size_t failed_bytes = 0;      // smallest workspace request that hipMalloc has refused (0: none); until fft_reserve / release
+    bool cache_enabled = false;   // the caller vouches that H and V only change through this library or are announced
+                                  // with tnmf_hip_ctx_invalidate (tnmf_hip_ctx_set_cache)
+    bool bound = false;           // H_base / V_base / geo / dtype describe the resident problem
+    bool explicit_bind = false;   // ... as told by tnmf_hip_ctx_bind (kept across foreign calls), not taken from a call
+    const void *H_base = nullptr;
+    const void *V_base = nullptr;
+    Geo geo = {};                 // geo.N = samples of the binding
+    int dtype = 0;
+    // per sample of the binding: the workspace holds ...
+    std::vector<unsigned char> T_ok;    // the row spectra of H[n]
+    std::vector<unsigned char> SH_ok;   // their column transforms (full spectra) as well
+    std::vector<unsigned char> V_ok;    // the row spectra of V[n]
+    std::vector<unsigned char> SV_ok;   // their full spectra as well
+    // row-transform passes over H / V: run, and skipped because the cache held every sample of the call
+    // (tnmf_hip_ctx_cache_counters)
+    unsigned long long h_runs = 0, h_hits = 0, v_runs = 0, v_hits = 0;
 };
 
 struct tnmf_hip_ctx {

@@ -66,8 +66,16 @@ int spectral_grad_W(const Geo &g, int dtype, const void *SH, const void *SV, con
 
 // shape support (2-D problems, transform length available for the activation shape, dtype instantiated)
 bool fft_has(const Geo &g, int dtype);
-void fft_invalidate(tnmf_hip_ctx *ctx);     // H and V may have changed
-void fft_invalidate_H(tnmf_hip_ctx *ctx);   // H has changed
+void fft_invalidate(tnmf_hip_ctx *ctx);     // H and V may have changed (every sample of the binding)
+// the g.N samples at H have changed (a slice of the bound activations: only their spectra are dropped; anything else: all)
+void fft_invalidate_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H);
+// The resident problem whose spectra the workspace mirrors (tnmf_hip_ctx_bind): g.N samples of activations at H and of
+// samples at V.  Calls on whole-sample slices of it share one cache with per-sample validity.
+void fft_bind(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H, const void *V);
+void fft_unbind(tnmf_hip_ctx *ctx);
+// samples of the resident problem a call on (g, H) belongs to: the bound sample count when H is a slice of the explicitly
+// bound activations, g.N otherwise (the dispatch decides the kernel family by the resident problem, not by the slice)
+int fft_bound_samples(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H);
 void fft_release(tnmf_hip_ctx *ctx);
 // pre-size the family's workspace for `g` (with_window: including the buffers of the fused FFT H update)
 int fft_reserve(tnmf_hip_ctx *ctx, const Geo &g, int dtype, bool with_window);

@@ -42,16 +42,28 @@ fft_run_fn lookup(int L) {
 
 bool use_mixed(const Geo &g, int dtype, bool grad_W);
 
-// workspace layout, in bytes
+// workspace layout, in bytes.  Sizes and offsets follow the RESIDENT problem (`gfull`: the binding, or the call itself);
+// the splits of the sample / atom loops follow the samples of the call (`g`, a mini-batch slice of it or the same).
 struct Lay {
     int Ly, Lx, KX, KXP, ngroups, nper, chunk, mgroups, mper;
     fft_run_fn rowf, colf;
     size_t csz;  // bytes of one complex element
     size_t T, SH, Tn, Tp, SV, SR, Ts, VT, RT, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total, total_no_window;
+    size_t sT, sSH, sS, sD;   // bytes per sample of T, SH, SV | SR, Ts | VT | RT
     bool resident;   // full spectra of H are kept (SH): the contractions stream them instead of transforming tiles
 };
 
-bool make_layout(const Geo &g, int dtype, Lay *l) {
+// split of the sample sum of the column-transform W-gradient kernel into groups
+void sample_groups(const Geo &g, int tiles, int *ngroups, int *nper) {
+    int ng = cdiv(2048, g.M * tiles);
+    if (ng > 16) ng = 16;
+    if (ng > g.N) ng = g.N;
+    if (ng < 1) ng = 1;
+    *nper = cdiv(g.N > 0 ? g.N : 1, ng);
+    *ngroups = cdiv(g.N > 0 ? g.N : 1, *nper);
+}
+
+bool make_layout(const Geo &gfull, const Geo &g, int dtype, Lay *l) {
     l->Ly = pick_len(g.Hy, dtype);
     l->Lx = pick_len(g.Hx, dtype);
     if (!l->Ly || !l->Lx) return false;
@@ -61,32 +73,30 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
     l->KXP = (int)align_up((size_t)l->KX, 16);
     l->csz = dtype == 0 ? 8 : 16;
     const int tiles = cdiv(l->KX, l->Ly > 384 ? 8 : 16);   // LenCfg<Ly>::col_tile of fft_kernels.h
-    int ng = cdiv(2048, g.M * tiles);
-    if (ng > 16) ng = 16;
-    if (ng > g.N) ng = g.N;
-    if (ng < 1) ng = 1;
-    l->nper = cdiv(g.N > 0 ? g.N : 1, ng);
-    l->ngroups = cdiv(g.N > 0 ? g.N : 1, l->nper);
+    int ngroups_full, nper_full;
+    sample_groups(gfull, tiles, &ngroups_full, &nper_full);
+    sample_groups(g, tiles, &l->ngroups, &l->nper);
     const size_t c = l->csz, kxp = (size_t)l->KXP;
-    const size_t nT = (size_t)g.N * g.M * g.Hy * kxp * c;
+    const size_t Nf = gfull.N > 0 ? gfull.N : 1;
+    l->sT = (size_t)g.M * g.Hy * kxp * c;
+    l->sSH = (size_t)g.M * l->Ly * kxp * c;
+    l->sS = (size_t)g.C * l->Ly * kxp * c;
+    l->sD = (size_t)g.C * g.Dy * kxp * c;
     // H half step in windows of `chunk` samples, which bounds the neg/pos row spectra (written by the column kernel, read
     // back by the row kernel right after) to 8 GB.  Measured at config 3: windows small enough for the 256 MiB Infinity
     // Cache are slower (launch tails: 24 MB 11.3 ms, 96 MB 7.3 ms, unwindowed 6.1 ms), so the window is as large as
     // the budget allows.
-    const size_t per_sample = (size_t)2 * g.M * g.Hy * kxp * c;
     size_t budget = (size_t)8 << 30;
     if (const char *e = tnmf_diag_env("TNMF_FFT_WINDOW_MB")) budget = (size_t)atol(e) << 20;
-    long chunk = (long)(budget / per_sample);
-    if (chunk < 1) chunk = 1;
-    if (chunk > g.N) chunk = g.N > 0 ? g.N : 1;
-    l->chunk = (int)chunk;
+    long chunk_full = (long)(budget / (2 * l->sT));
+    if (chunk_full < 1) chunk_full = 1;
+    if (chunk_full > (long)Nf) chunk_full = (long)Nf;
+    l->chunk = (int)(chunk_full > g.N && g.N > 0 ? g.N : chunk_full);
     int mg = cdiv(1024, l->chunk * cdiv(l->KX, 16) * 2);   // the H-gradient kernel always takes 16-column tiles
     if (mg > g.M) mg = g.M;
     if (mg < 1) mg = 1;
     l->mper = cdiv(g.M, mg);
     l->mgroups = cdiv(g.M, l->mper);
-    const size_t nTc = (size_t)l->chunk * g.M * g.Hy * kxp * c;
-    const size_t nS = (size_t)g.N * g.C * l->Ly * kxp * c;
     const size_t nSW = (size_t)g.M * g.C * l->Ly * kxp * c;
     size_t o = 0;
     auto take = [&o](size_t bytes) {
@@ -94,32 +104,41 @@ bool make_layout(const Geo &g, int dtype, Lay *l) {
         o += align_up(bytes, 256);
         return at;
     };
-    l->T = take(nT);
+    // (+ 64 slack rows: k_mix_reconstruct reads up to S + Ay - 1 rows past the last plane under outputs it drops)
+    l->T = take(Nf * l->sT + (size_t)64 * kxp * c);
     // Problems the mixed kernels do not cover (several channels, tall atoms) keep the full spectra of H resident: one
     // column-transform pass per H, then every contraction is a plain streaming kernel (fft_spectral.hip)
     l->resident = !(use_mixed(g, dtype, false) && use_mixed(g, dtype, true));
-    l->SH = take(l->resident ? (size_t)g.N * g.M * l->Ly * kxp * c : 0);
-    l->SV = take(nS);
-    l->SR = take(nS);
-    l->Ts = take((size_t)g.N * g.C * g.Dy * kxp * c);
-    l->VT = take((size_t)g.N * g.C * g.Dy * kxp * c);   // row spectra of V (kept) and of R
-    l->RT = take((size_t)g.N * g.C * g.Dy * kxp * c);
+    l->SH = take(l->resident ? Nf * l->sSH : 0);
+    l->SV = take(Nf * l->sS);
+    l->SR = take(Nf * l->sS);
+    l->Ts = take(Nf * l->sD);
+    l->VT = take(Nf * l->sD);   // row spectra of V (kept) and of R
+    l->RT = take(Nf * l->sD);
     l->SW = take(nSW);
     l->SWf = take(nSW);
     l->TW = take((size_t)2 * g.M * g.C * g.Ay * kxp * c);
     l->Wt = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
     // partial W-gradient spectra: [groups][M*C][Ly][KXP] for the column-transform kernel, [<= kMixMaxGroups groups]
     // [M*C][Ay][KXP] for the mixed kernel
-    const size_t nG = std::max(nSW * l->ngroups, (size_t)kMixMaxGroups * g.M * g.C * g.Ay * kxp * c);
+    const size_t nG = std::max(nSW * ngroups_full, (size_t)kMixMaxGroups * g.M * g.C * g.Ay * kxp * c);
     l->Gn = take(nG);
     l->Gp = take(nG);
     l->Gs = take(nSW * 2);
     l->Wo = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
     l->total_no_window = o;
+    const size_t nTc = (size_t)chunk_full * l->sT;
     l->Tn = take(nTc);   // the window buffers of the H half step come last: callers that never run it (the hybrid
     l->Tp = take(nTc);   // dispatch) do not pay for them
     l->total = o;
     return true;
+}
+
+void clear_flags(FftState &f) {
+    std::fill(f.T_ok.begin(), f.T_ok.end(), 0);
+    std::fill(f.SH_ok.begin(), f.SH_ok.end(), 0);
+    std::fill(f.V_ok.begin(), f.V_ok.end(), 0);
+    std::fill(f.SV_ok.begin(), f.SV_ok.end(), 0);
 }
 
 int ensure_ws(tnmf_hip_ctx *ctx, size_t bytes) {
@@ -128,22 +147,34 @@ int ensure_ws(tnmf_hip_ctx *ctx, size_t bytes) {
     // A request at least as large as one that already failed is refused at once: under TNMF_PATH_AUTO the callers fall
     // back to the direct kernels, and must not pay a multi-GB hipMalloc attempt on every call.
     if (f.failed_bytes && bytes >= f.failed_bytes) return TNMF_E_WORKSPACE;
-    // the larger buffer is allocated BEFORE the current one is released, so a failure leaves the working one in place
+    // the larger buffer is allocated BEFORE the current one is released, so a failure leaves the working one in place;
+    // when old + new do not fit side by side the old order (release, then allocate) is tried once, and only if that
+    // fails too is the size remembered as refused (until tnmf_hip_ctx_reserve: the caller may have freed memory since)
     const size_t want = align_up(bytes, 1 << 20);
     void *bigger = nullptr;
     if (hipMalloc(&bigger, want) != hipSuccess) {
         (void)hipGetLastError();
-        f.failed_bytes = bytes;
-        return TNMF_E_WORKSPACE;
+        bigger = nullptr;
+        if (!f.ws) {
+            f.failed_bytes = bytes;
+            return TNMF_E_WORKSPACE;
+        }
     }
     if (f.ws) {
         TNMF_HIP_TRY(hipDeviceSynchronize());
         TNMF_HIP_TRY(hipFree(f.ws));
+        f.ws = nullptr;
+        f.ws_bytes = 0;
+        clear_flags(f);
+    }
+    if (!bigger && hipMalloc(&bigger, want) != hipSuccess) {
+        (void)hipGetLastError();
+        f.failed_bytes = bytes;
+        return TNMF_E_WORKSPACE;
     }
     f.ws = bigger;
     f.ws_bytes = want;
-    f.T_valid = f.SH_valid = false;
-    f.V_valid = f.SV_valid = false;
+    clear_flags(f);
     return TNMF_OK;
 }
 
@@ -281,24 +312,108 @@ int spectra_W(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const vo
     return TNMF_OK;
 }
 
-bool T_is_current(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
-    const FftState &f = ctx->fft;
-    return f.cache_enabled && f.T_valid && f.T_owner == H && f.T_dtype == dtype && f.T_geo.N == g.N &&
-           f.T_geo.M == g.M && f.T_geo.C == g.C && f.T_geo.Dy == g.Dy && f.T_geo.Dx == g.Dx && f.T_geo.Ay == g.Ay &&
-           f.T_geo.Ax == g.Ax && f.T_geo.Hs == g.Hs;
+// ---- binding and per-sample validity ---------------------------------------------------------------------------------
+
+inline size_t esz_of(int dtype) { return dtype == 0 ? 4 : 8; }
+
+bool same_shape(const Geo &a, const Geo &b) {
+    return a.M == b.M && a.C == b.C && a.Dy == b.Dy && a.Dx == b.Dx && a.Ay == b.Ay && a.Ax == b.Ax && a.Hs == b.Hs;
 }
 
-void T_mark(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
+void bind(FftState &f, const Geo &g, int dtype, const void *H, const void *V, bool explicit_bind) {
+    f.bound = true;
+    f.explicit_bind = explicit_bind;
+    f.H_base = H;
+    f.V_base = V;
+    f.geo = g;
+    f.dtype = dtype;
+    const size_t n = g.N > 0 ? (size_t)g.N : 0;
+    f.T_ok.assign(n, 0);
+    f.SH_ok.assign(n, 0);
+    f.V_ok.assign(n, 0);
+    f.SV_ok.assign(n, 0);
+}
+
+// where the samples of a call sit in the per-sample arrays of the workspace
+struct Slot {
+    int n0;          // first sample of the call within the binding (0: the call is not a slice of the bound problem)
+    bool cached;     // H of the call is a slice of the bound activations: validity flags apply and results are recorded
+    bool v_cached;   // likewise V
+};
+
+Slot locate(FftState &f, const Geo &g, int dtype, const void *H, const void *V) {
+    Slot sl = {0, false, false};
+    if (!f.cache_enabled || !f.bound || dtype != f.dtype || !same_shape(f.geo, g) || g.N <= 0) return sl;
+    const size_t es = esz_of(dtype);
+    const size_t hb = (size_t)g.M * g.Hy * g.Hs * es, vb = (size_t)g.C * g.Dy * g.Dx * es;
+    long n0 = -1;
+    if (H) {
+        const ptrdiff_t d = static_cast<const char *>(H) - static_cast<const char *>(f.H_base);
+        if (!f.H_base || d < 0 || (size_t)d % hb) return sl;
+        n0 = (long)((size_t)d / hb);
+    } else if (V && f.V_base) {   // (the H gradient takes no H: the samples locate the call)
+        const ptrdiff_t d = static_cast<const char *>(V) - static_cast<const char *>(f.V_base);
+        if (d < 0 || (size_t)d % vb) return sl;
+        n0 = (long)((size_t)d / vb);
+    }
+    if (n0 < 0 || n0 + g.N > f.geo.N) return sl;
+    sl.n0 = (int)n0;
+    sl.cached = true;
+    if (V) {
+        if (!f.V_base) {   // binding taken from a call that had no V: adopt the samples now
+            f.V_base = static_cast<const char *>(V) - (size_t)n0 * vb;
+            std::fill(f.V_ok.begin(), f.V_ok.end(), 0);
+            std::fill(f.SV_ok.begin(), f.SV_ok.end(), 0);
+        }
+        sl.v_cached = static_cast<const char *>(V) == static_cast<const char *>(f.V_base) + (size_t)n0 * vb;
+    }
+    return sl;
+}
+
+bool all_ok(const std::vector<unsigned char> &v, int n0, int n) {
+    for (int i = n0; i < n0 + n; ++i)
+        if (!v[i]) return false;
+    return true;
+}
+void set_ok(std::vector<unsigned char> &v, int n0, int n, unsigned char val) {
+    for (int i = n0; i < n0 + n && i < (int)v.size(); ++i) v[i] = val;
+}
+
+// per-call view of the workspace: layout + the pointers of the call's sample range
+struct Call {
+    Lay l;
+    Slot sl;
+    char *T, *SH, *SV, *SR, *Ts, *VT, *RT;
+};
+
+int prepare(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H, const void *V, Call *c, bool window = false) {
+    if (!fft_has(g, dtype)) return TNMF_E_UNSUPPORTED;
     FftState &f = ctx->fft;
-    f.T_valid = f.cache_enabled;
-    f.SH_valid = false;
-    f.T_owner = H;
-    f.T_geo = g;
-    f.T_dtype = dtype;
-}
-
-bool same_geo(const Geo &a, const Geo &b) {
-    return a.N == b.N && a.M == b.M && a.C == b.C && a.Dy == b.Dy && a.Dx == b.Dx && a.Ay == b.Ay && a.Ax == b.Ax;
+    c->sl = locate(f, g, dtype, H, V);
+    if (!c->sl.cached) {
+        if (f.cache_enabled && !f.explicit_bind && (H || V)) {
+            // no binding told by the caller: the operands of this call become the resident problem (the spectra of the
+            // activations transformed or updated last are reused while the same pointers and geometry come back)
+            bind(f, g, dtype, H, V, false);
+            c->sl = {0, H != nullptr, V != nullptr};
+        } else {
+            clear_flags(f);   // a foreign problem passes through the workspace: nothing of the binding survives it
+        }
+    }
+    const bool in_binding = c->sl.cached || c->sl.v_cached;
+    if (!make_layout(in_binding ? f.geo : g, g, dtype, &c->l)) return TNMF_E_UNSUPPORTED;
+    CHECK(ensure_ws(ctx, window ? c->l.total : c->l.total_no_window));
+    const Lay &l = c->l;
+    const size_t n0 = (size_t)c->sl.n0;
+    c->T = at(ctx, l.T) + n0 * l.sT;
+    c->SH = at(ctx, l.SH) + n0 * l.sSH;
+    c->SV = at(ctx, l.SV) + n0 * l.sS;
+    c->SR = at(ctx, l.SR) + n0 * l.sS;
+    c->Ts = at(ctx, l.Ts) + n0 * l.sD;
+    c->VT = at(ctx, l.VT) + n0 * l.sD;
+    c->RT = at(ctx, l.RT) + n0 * l.sD;
+    ctx->last_path = "fft";
+    return TNMF_OK;
 }
 
 // rows only: real planes [planes][rows][cols] -> row spectra
@@ -325,57 +440,64 @@ int columns_of(const Geo &g, const Lay &l, int dtype, const void *Tsrc, int plan
     return l.colf(kFftColsFwd, dtype, &b, s);
 }
 
-// spectra of the samples: row spectra into VT always, full spectra into SV on demand (both skipped when the cache
-// holds them: V never changes during a fit)
-int spectra_V(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, bool full, hipStream_t s) {
+// spectra of the samples: row spectra into VT always, full spectra into SV on demand (both skipped for the samples whose
+// spectra the cache holds: V never changes during a fit)
+int spectra_V(tnmf_hip_ctx *ctx, const Geo &g, const Call &c, int dtype, const void *V, bool full, hipStream_t s) {
     FftState &f = ctx->fft;
-    const bool hit = f.cache_enabled && f.V_valid && f.V_owner == V && f.V_dtype == dtype && same_geo(f.V_geo, g);
+    const Lay &l = c.l;
+    const bool track = c.sl.v_cached && f.cache_enabled;
+    const bool hit = track && all_ok(f.V_ok, c.sl.n0, g.N);
+    ++(hit ? f.v_hits : f.v_runs);
     if (!hit) {
-        f.V_valid = f.SV_valid = false;
-        CHECK(forward_rows(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, at(ctx, l.VT), s));
-        f.V_valid = f.cache_enabled;
-        f.V_owner = V;
-        f.V_geo = g;
-        f.V_dtype = dtype;
+        if (track) {
+            set_ok(f.V_ok, c.sl.n0, g.N, 0);
+            set_ok(f.SV_ok, c.sl.n0, g.N, 0);
+        }
+        CHECK(forward_rows(g, l, dtype, V, g.N * g.C, g.Dy, g.Dx, c.VT, s));
+        if (track) set_ok(f.V_ok, c.sl.n0, g.N, 1);
     }
-    if (full && !(hit && f.SV_valid)) {
-        CHECK(columns_of(g, l, dtype, at(ctx, l.VT), g.N * g.C, g.Dy, at(ctx, l.SV), s));
-        f.SV_valid = f.cache_enabled;
+    if (full && !(hit && all_ok(f.SV_ok, c.sl.n0, g.N))) {
+        CHECK(columns_of(g, l, dtype, c.VT, g.N * g.C, g.Dy, c.SV, s));
+        if (track) set_ok(f.SV_ok, c.sl.n0, g.N, 1);
     }
     return TNMF_OK;
 }
 
-// row spectra of H into the workspace (skipped when the cache holds them)
-int rows_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *H, hipStream_t s) {
-    if (T_is_current(ctx, g, dtype, H)) return TNMF_OK;
-    ctx->fft.SH_valid = false;
-    FftArgs a = base_args(g, l);
+// row spectra of H into the workspace (skipped when the cache holds them for every sample of the call)
+int rows_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Call &c, int dtype, const void *H, hipStream_t s) {
+    FftState &f = ctx->fft;
+    const bool track = c.sl.cached && f.cache_enabled;
+    if (track && all_ok(f.T_ok, c.sl.n0, g.N)) {
+        ++f.h_hits;
+        return TNMF_OK;
+    }
+    ++f.h_runs;
+    if (track) {
+        set_ok(f.T_ok, c.sl.n0, g.N, 0);
+        set_ok(f.SH_ok, c.sl.n0, g.N, 0);
+    }
+    FftArgs a = base_args(g, c.l);
     a.src0 = H;
-    a.dst0 = at(ctx, l.T);
+    a.dst0 = c.T;
     a.planes = g.N * g.M;
     a.rows = g.Hy;
     a.cols = g.Hx;
     a.ld_src = g.Hs;   // rows of H may be padded (tnmf_hip_geom.h_row_stride)
     a.ps_src = (long)g.Hy * g.Hs;
-    a.ps_dst = (long)g.Hy * l.KXP;
-    CHECK(l.rowf(kFftRowsFwd, dtype, &a, s));
-    T_mark(ctx, g, dtype, H);
+    a.ps_dst = (long)g.Hy * c.l.KXP;
+    CHECK(c.l.rowf(kFftRowsFwd, dtype, &a, s));
+    if (track) set_ok(f.T_ok, c.sl.n0, g.N, 1);
     return TNMF_OK;
 }
 
 // full spectra of H (column transforms of its row spectra) into SH, once per H
-int spectra_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *H, hipStream_t s) {
-    CHECK(rows_of_H(ctx, g, l, dtype, H, s));
-    if (ctx->fft.SH_valid && ctx->fft.T_valid) return TNMF_OK;
-    CHECK(columns_of(g, l, dtype, at(ctx, l.T), g.N * g.M, g.Hy, at(ctx, l.SH), s));
-    ctx->fft.SH_valid = ctx->fft.T_valid;   // only as good as the row spectra it came from
-    return TNMF_OK;
-}
-
-int prepare(tnmf_hip_ctx *ctx, const Geo &g, int dtype, Lay *l, bool window = false) {
-    if (!fft_has(g, dtype) || !make_layout(g, dtype, l)) return TNMF_E_UNSUPPORTED;
-    CHECK(ensure_ws(ctx, window ? l->total : l->total_no_window));
-    ctx->last_path = "fft";
+int spectra_of_H(tnmf_hip_ctx *ctx, const Geo &g, const Call &c, int dtype, const void *H, hipStream_t s) {
+    FftState &f = ctx->fft;
+    CHECK(rows_of_H(ctx, g, c, dtype, H, s));
+    const bool track = c.sl.cached && f.cache_enabled;
+    if (track && all_ok(f.SH_ok, c.sl.n0, g.N)) return TNMF_OK;
+    CHECK(columns_of(g, c.l, dtype, c.T, g.N * g.M, g.Hy, c.SH, s));
+    if (track) set_ok(f.SH_ok, c.sl.n0, g.N, 1);   // (only as good as the row spectra they came from: cleared with them)
     return TNMF_OK;
 }
 
@@ -391,17 +513,50 @@ bool fft_has(const Geo &g, int dtype) {
     return pick_len(g.Hy, dtype) != 0 && pick_len(g.Hx, dtype) != 0;
 }
 
-void fft_invalidate_H(tnmf_hip_ctx *ctx) { ctx->fft.T_valid = ctx->fft.SH_valid = false; }
-
-void fft_invalidate(tnmf_hip_ctx *ctx) {
-    ctx->fft.T_valid = ctx->fft.SH_valid = false;
-    ctx->fft.V_valid = false;
-    ctx->fft.SV_valid = false;
+void fft_bind(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H, const void *V) {
+    bind(ctx->fft, g, dtype, H, V, true);
 }
+
+void fft_unbind(tnmf_hip_ctx *ctx) {
+    FftState &f = ctx->fft;
+    f.bound = f.explicit_bind = false;
+    f.H_base = f.V_base = nullptr;
+    f.T_ok.clear();
+    f.SH_ok.clear();
+    f.V_ok.clear();
+    f.SV_ok.clear();
+}
+
+int fft_bound_samples(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
+    const FftState &f = ctx->fft;
+    if (!f.cache_enabled || !f.bound || !f.explicit_bind || dtype != f.dtype || !same_shape(f.geo, g) || !H || !f.H_base)
+        return g.N;
+    const size_t hb = (size_t)g.M * g.Hy * g.Hs * esz_of(dtype);
+    const ptrdiff_t d = static_cast<const char *>(H) - static_cast<const char *>(f.H_base);
+    if (d < 0 || (size_t)d % hb || (long)((size_t)d / hb) + g.N > f.geo.N) return g.N;
+    return f.geo.N;
+}
+
+void fft_invalidate_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
+    FftState &f = ctx->fft;
+    const Slot sl = locate(f, g, dtype, H, nullptr);
+    if (sl.cached) {
+        set_ok(f.T_ok, sl.n0, g.N, 0);
+        set_ok(f.SH_ok, sl.n0, g.N, 0);
+    } else {
+        std::fill(f.T_ok.begin(), f.T_ok.end(), 0);
+        std::fill(f.SH_ok.begin(), f.SH_ok.end(), 0);
+    }
+}
+
+void fft_invalidate(tnmf_hip_ctx *ctx) { clear_flags(ctx->fft); }
 
 int fft_reserve(tnmf_hip_ctx *ctx, const Geo &g, int dtype, bool with_window) {
     Lay l;
-    if (!fft_has(g, dtype) || !make_layout(g, dtype, &l)) return TNMF_E_UNSUPPORTED;
+    ctx->fft.failed_bytes = 0;   // an explicit request: try again even if this size was refused before
+    const FftState &f = ctx->fft;
+    const bool in_binding = f.bound && f.dtype == dtype && same_shape(f.geo, g) && f.geo.N >= g.N;
+    if (!fft_has(g, dtype) || !make_layout(in_binding ? f.geo : g, g, dtype, &l)) return TNMF_E_UNSUPPORTED;
     return ensure_ws(ctx, with_window ? l.total : l.total_no_window);
 }
 
@@ -410,69 +565,69 @@ void fft_release(tnmf_hip_ctx *ctx) {
     ctx->fft.ws = nullptr;
     ctx->fft.ws_bytes = 0;
     ctx->fft.failed_bytes = 0;
-    ctx->fft.T_valid = ctx->fft.SH_valid = false;
-    ctx->fft.V_valid = false;
-    ctx->fft.SV_valid = false;
+    clear_flags(ctx->fft);
 }
 
 int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, bool nonneg,
                     hipStream_t s) {
-    Lay l;
-    CHECK(prepare(ctx, g, dtype, &l));
-    CHECK(rows_of_H(ctx, g, l, dtype, H, s));
+    Call c;
+    CHECK(prepare(ctx, g, dtype, H, nullptr, &c));
+    const Lay &l = c.l;
+    CHECK(rows_of_H(ctx, g, c, dtype, H, s));
     if (use_mixed(g, dtype, false)) {
         // transform along x only; the atom rows are contracted directly (fft_mixed.hip)
         CHECK(scaled_W(ctx, g, l, dtype, W, 1.0 / l.Lx, s));
         CHECK(forward_rows(g, l, dtype, at(ctx, l.Wt), g.M * g.C, g.Ay, g.Ax, at(ctx, l.TW), s));
-        CHECK(mixed_reconstruct(g, at(ctx, l.T), at(ctx, l.TW), at(ctx, l.Ts), l.KX, l.KXP, s));
+        CHECK(mixed_reconstruct(g, c.T, at(ctx, l.TW), c.Ts, l.KX, l.KXP, s));
     } else {
         CHECK(spectra_W(ctx, g, l, dtype, W, true, false, s));
         if (use_resident(l)) {
-            CHECK(spectra_of_H(ctx, g, l, dtype, H, s));
-            CHECK(spectral_contract_R(g, dtype, at(ctx, l.SH), at(ctx, l.SW), at(ctx, l.SR), l.Ly, l.KX, l.KXP, s));
+            CHECK(spectra_of_H(ctx, g, c, dtype, H, s));
+            CHECK(spectral_contract_R(g, dtype, c.SH, at(ctx, l.SW), c.SR, l.Ly, l.KX, l.KXP, s));
         } else {
             FftArgs a = base_args(g, l);
-            a.src0 = at(ctx, l.T);
+            a.src0 = c.T;
             a.src1 = at(ctx, l.SW);
-            a.dst0 = at(ctx, l.SR);
+            a.dst0 = c.SR;
             CHECK(l.colf(kFftContractR, dtype, &a, s));
         }
         FftArgs b = base_args(g, l);
-        b.src0 = at(ctx, l.SR);
-        b.dst0 = at(ctx, l.Ts);
+        b.src0 = c.SR;
+        b.dst0 = c.Ts;
         b.planes = g.N * g.C;
         b.rows = g.Dy;
         b.yoff = g.Ay - 1;
         CHECK(l.colf(kFftColsInv, dtype, &b, s));
     }
-    FftArgs c = base_args(g, l);
-    c.src0 = at(ctx, l.Ts);
-    c.dst0 = R;
-    c.planes = g.N * g.C;
-    c.rows = g.Dy;
-    c.cols = g.Dx;
-    c.xoff = g.Ax - 1;
-    c.ld_dst = g.Dx;
-    c.ps_dst = (long)g.Dy * g.Dx;
-    c.clamp0 = nonneg ? 1 : 0;
-    return l.rowf(kFftRowsInv, dtype, &c, s);
+    FftArgs d = base_args(g, l);
+    d.src0 = c.Ts;
+    d.dst0 = R;
+    d.planes = g.N * g.C;
+    d.rows = g.Dy;
+    d.cols = g.Dx;
+    d.xoff = g.Ax - 1;
+    d.ld_dst = g.Dx;
+    d.ps_dst = (long)g.Dy * g.Dx;
+    d.clamp0 = nonneg ? 1 : 0;
+    return l.rowf(kFftRowsInv, dtype, &d, s);
 }
 
 namespace {
 
 // spectra of V and R and of the flipped W: what the H-gradient column kernel contracts
-int grad_H_spectra(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, const void *V, const void *R,
+int grad_H_spectra(tnmf_hip_ctx *ctx, const Geo &g, const Call &c, int dtype, const void *V, const void *R,
                    const void *W, hipStream_t s) {
-    CHECK(spectra_W(ctx, g, l, dtype, W, false, true, s));
-    CHECK(spectra_V(ctx, g, l, dtype, V, true, s));
-    return forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s);
+    CHECK(spectra_W(ctx, g, c.l, dtype, W, false, true, s));
+    CHECK(spectra_V(ctx, g, c, dtype, V, true, s));
+    return forward_planes(g, c.l, dtype, R, g.N * g.C, g.Dy, g.Dx, c.Ts, c.SR, s);
 }
 
-// neg/pos row spectra of the samples [n0, n0+cnt) into the window buffers
-int grad_H_window(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, int n0, int cnt, hipStream_t s) {
+// neg/pos row spectra of the call's samples [n0, n0+cnt) into the window buffers
+int grad_H_window(tnmf_hip_ctx *ctx, const Geo &g, const Call &c, int dtype, int n0, int cnt, hipStream_t s) {
+    const Lay &l = c.l;
     FftArgs a = base_args(g, l);
-    a.src0 = at(ctx, l.SV);
-    a.src1 = at(ctx, l.SR);
+    a.src0 = c.SV;
+    a.src1 = c.SR;
     a.src2 = at(ctx, l.SWf);
     a.dst0 = at(ctx, l.Tn);
     a.dst1 = at(ctx, l.Tp);
@@ -488,13 +643,14 @@ int grad_H_window(tnmf_hip_ctx *ctx, const Geo &g, const Lay &l, int dtype, int 
 int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *neg,
                void *pos, hipStream_t s) {
     if (g.Dy == 1 && g.Ay == 1) return TNMF_E_UNSUPPORTED;   // 1-D: row-transform half only (fft_has)
-    Lay l;
-    CHECK(prepare(ctx, g, dtype, &l, true));
-    CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));
+    Call c;
+    CHECK(prepare(ctx, g, dtype, nullptr, V, &c, true));
+    const Lay &l = c.l;
+    CHECK(grad_H_spectra(ctx, g, c, dtype, V, R, W, s));
     const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hx;
     for (int n0 = 0; n0 < g.N; n0 += l.chunk) {
         const int cnt = g.N - n0 < l.chunk ? g.N - n0 : l.chunk;
-        CHECK(grad_H_window(ctx, g, l, dtype, n0, cnt, s));
+        CHECK(grad_H_window(ctx, g, c, dtype, n0, cnt, s));
         FftArgs a = base_args(g, l);
         a.src0 = at(ctx, l.Tn);
         a.src1 = at(ctx, l.Tp);
@@ -514,19 +670,25 @@ int fft_grad_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
 int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *H,
                  double reg, hipStream_t s) {
     if (g.Dy == 1 && g.Ay == 1) return TNMF_E_UNSUPPORTED;   // 1-D: row-transform half only (fft_has)
-    Lay l;
-    CHECK(prepare(ctx, g, dtype, &l, true));
-    CHECK(grad_H_spectra(ctx, g, l, dtype, V, R, W, s));
-    ctx->fft.T_valid = ctx->fft.SH_valid = false;
-    const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hs, tplane = (size_t)g.M * g.Hy * l.KXP;
+    Call c;
+    CHECK(prepare(ctx, g, dtype, H, V, &c, true));
+    const Lay &l = c.l;
+    FftState &f = ctx->fft;
+    const bool track = c.sl.cached && f.cache_enabled;
+    CHECK(grad_H_spectra(ctx, g, c, dtype, V, R, W, s));
+    if (track) {
+        set_ok(f.T_ok, c.sl.n0, g.N, 0);
+        set_ok(f.SH_ok, c.sl.n0, g.N, 0);
+    }
+    const size_t esz = l.csz / 2, hplane = (size_t)g.M * g.Hy * g.Hs;
     for (int n0 = 0; n0 < g.N; n0 += l.chunk) {
         const int cnt = g.N - n0 < l.chunk ? g.N - n0 : l.chunk;
-        CHECK(grad_H_window(ctx, g, l, dtype, n0, cnt, s));
+        CHECK(grad_H_window(ctx, g, c, dtype, n0, cnt, s));
         FftArgs a = base_args(g, l);
         a.src0 = at(ctx, l.Tn);
         a.src1 = at(ctx, l.Tp);
         a.dst0 = static_cast<char *>(H) + (size_t)n0 * hplane * esz;
-        a.dst1 = at(ctx, l.T) + (size_t)n0 * tplane * l.csz;
+        a.dst1 = c.T + (size_t)n0 * l.sT;
         a.planes = cnt * g.M;
         a.rows = g.Hy;
         a.cols = g.Hx;
@@ -536,7 +698,7 @@ int fft_update_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, cons
         a.reg = reg;
         CHECK(l.rowf(kFftRowsMu, dtype, &a, s));
     }
-    T_mark(ctx, g, dtype, H);
+    if (track) set_ok(f.T_ok, c.sl.n0, g.N, 1);   // the kernel left the row spectra of the new H behind
     return TNMF_OK;
 }
 
@@ -567,15 +729,16 @@ int mix_groups(const tnmf_hip_ctx *ctx, const Geo &g, const Lay &l) {
 
 int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *H, void *neg,
                void *pos, bool nonneg, hipStream_t s) {
-    Lay l;
-    CHECK(prepare(ctx, g, dtype, &l));
-    CHECK(rows_of_H(ctx, g, l, dtype, H, s));
+    Call c;
+    CHECK(prepare(ctx, g, dtype, H, V, &c));
+    const Lay &l = c.l;
+    CHECK(rows_of_H(ctx, g, c, dtype, H, s));
     const bool mixed = use_mixed(g, dtype, true);
-    CHECK(spectra_V(ctx, g, l, dtype, V, !mixed, s));
+    CHECK(spectra_V(ctx, g, c, dtype, V, !mixed, s));
     const int planes = 2 * g.M * g.C;
     if (mixed) {
         // transform along x only; the Ay lags along y are accumulated directly (fft_mixed.hip)
-        CHECK(forward_rows(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.RT), s));
+        CHECK(forward_rows(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, c.RT, s));
         // sample groups = partial sums (mix_groups below)
         int ng_want = mix_groups(ctx, g, l);
         if (const char *e = tnmf_diag_env("TNMF_MIX_GROUPS")) ng_want = atoi(e);   // diagnostic builds only
@@ -584,8 +747,7 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
         const int nper = cdiv(g.N, ng);
         ng = cdiv(g.N, nper);
         const int ngpad = (int)align_up((size_t)ng, 4);   // whole blocks of 4 groups; the extra groups write zeros
-        CHECK(mixed_grad_W(g, at(ctx, l.T), at(ctx, l.VT), at(ctx, l.RT), at(ctx, l.Gn), at(ctx, l.Gp), l.KX, l.KXP,
-                           ngpad, nper, s));
+        CHECK(mixed_grad_W(g, c.T, c.VT, c.RT, at(ctx, l.Gn), at(ctx, l.Gp), l.KX, l.KXP, ngpad, nper, s));
         const long count = (long)g.M * g.C * g.Ay * l.KXP;
         char *out = at(ctx, l.TW);   // [2*M*C][Ay][KXP]
         hipLaunchKernelGGL(k_fft_sum_groups<float>, dim3((unsigned)((count + 63) / 64), 2), dim3(64), 0, s,
@@ -593,16 +755,16 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
                            (cplx<float> *)(out + (size_t)count * l.csz), count, ngpad, 1.0 / l.Lx);
         TNMF_LAUNCH_CHECK();
     } else {
-        CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, at(ctx, l.Ts), at(ctx, l.SR), s));
+        CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, c.Ts, c.SR, s));
         if (use_resident(l)) {
-            CHECK(spectra_of_H(ctx, g, l, dtype, H, s));
-            CHECK(spectral_grad_W(g, dtype, at(ctx, l.SH), at(ctx, l.SV), at(ctx, l.SR), at(ctx, l.Gn), at(ctx, l.Gp),
-                                  l.Ly, l.KX, l.KXP, l.ngroups, l.nper, s));
+            CHECK(spectra_of_H(ctx, g, c, dtype, H, s));
+            CHECK(spectral_grad_W(g, dtype, c.SH, c.SV, c.SR, at(ctx, l.Gn), at(ctx, l.Gp), l.Ly, l.KX, l.KXP, l.ngroups,
+                                  l.nper, s));
         } else {
             FftArgs a = base_args(g, l);
-            a.src0 = at(ctx, l.T);
-            a.src1 = at(ctx, l.SV);
-            a.src2 = at(ctx, l.SR);
+            a.src0 = c.T;
+            a.src1 = c.SV;
+            a.src2 = c.SR;
             a.dst0 = at(ctx, l.Gn);
             a.dst1 = at(ctx, l.Gp);
             a.ngroups = l.ngroups;
@@ -634,16 +796,16 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
         b.yoff = 0;
         CHECK(l.colf(kFftColsInv, dtype, &b, s));
     }
-    FftArgs c = base_args(g, l);
-    c.src0 = at(ctx, l.TW);
-    c.dst0 = at(ctx, l.Wo);
-    c.planes = planes;
-    c.rows = g.Ay;
-    c.cols = g.Ax;
-    c.xoff = 0;
-    c.ld_dst = g.Ax;
-    c.ps_dst = (long)g.Ay * g.Ax;
-    CHECK(l.rowf(kFftRowsInv, dtype, &c, s));
+    FftArgs d = base_args(g, l);
+    d.src0 = at(ctx, l.TW);
+    d.dst0 = at(ctx, l.Wo);
+    d.planes = planes;
+    d.rows = g.Ay;
+    d.cols = g.Ax;
+    d.xoff = 0;
+    d.ld_dst = g.Ax;
+    d.ps_dst = (long)g.Ay * g.Ax;
+    CHECK(l.rowf(kFftRowsInv, dtype, &d, s));
     const int per = g.M * g.C * g.Ay * g.Ax;
     const char *wo = at(ctx, l.Wo);
     if (dtype == 0) {

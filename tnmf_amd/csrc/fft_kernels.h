@@ -7,6 +7,7 @@
 //   full spectra  [plane][L][KXP]     c, ky digit-reversed  "S": what the pointwise contractions work on
 // A row kernel works on NB row pairs (two real rows = one complex sequence), a column kernel on a tile of 16 kx.
 #pragma once
+#include <atomic>
 #include "fft.h"
 #include "fft_engine.h"
 
@@ -687,14 +688,16 @@ int set_lds_limit(K kernel, size_t bytes) {
 // the dynamic-LDS opt-in belongs to the (function, device) pair: one flag per device, not one per process
 #define TNMF_FFT_LAUNCH(kernel, grid, threads, lds)                         \
     do {                                                                    \
-        static unsigned long long attr_done = 0;                            \
+        static std::atomic<unsigned long long> attr_done{0};                \
         int dev_ = 0;                                                       \
         TNMF_HIP_TRY(hipGetDevice(&dev_));                                  \
         const unsigned long long bit_ = 1ull << (dev_ & 63);                \
-        if (!(attr_done & bit_)) {                                          \
+        if (!(attr_done.load(std::memory_order_acquire) & bit_)) {          \
+            /* contexts on different devices may get here from different threads: setting the attribute twice is */ \
+            /* harmless, losing another device's bit is not -- hence the atomic OR */                                 \
             const int _rc = set_lds_limit(kernel, (lds));                   \
             if (_rc != TNMF_OK) return _rc;                                 \
-            attr_done |= bit_;                                              \
+            attr_done.fetch_or(bit_, std::memory_order_release);            \
         }                                                                   \
         hipLaunchKernelGGL(kernel, grid, dim3(threads), (lds), s, *a);      \
         TNMF_LAUNCH_CHECK();                                                \

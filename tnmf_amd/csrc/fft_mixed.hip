@@ -63,8 +63,11 @@ __global__ __launch_bounds__(kMixCols *STRIPS, 2) void k_mix_reconstruct(const c
         for (int y = 0; y < S; ++y) acc[c][y] = {0, 0};
     // Addresses: a buffer descriptor per plane (wave-uniform, scalar registers), a scalar row offset, and ONE per-lane
     // byte offset (first row of the strip, kx) that never changes -- no vector address arithmetic and no offset
-    // registers.  Rows past the plane (y0 + r >= Hy: only under outputs that are never stored) fail the descriptor's
-    // range check and read as zero.  The rows of the next atom are fetched while the current ones are multiplied.
+    // registers.  Rows past the plane (y0 + r >= Hy) are read only under outputs that are never stored (output row y needs
+    // rows up to y + AY - 1 <= Hy - 1 whenever y < Dy).  The descriptor's range check does NOT catch them -- on gfx9 raw
+    // buffers it covers the vector offset only, not the scalar one -- so they come from the next plane or, behind the last
+    // plane, from the slack rows the workspace layout keeps after T (fft.hip: make_layout); whatever they hold only
+    // reaches accumulators that are dropped.  The rows of the next atom are fetched while the current ones are multiplied.
     static_assert(sizeof(cplx<T>) == 8, "float spectra");
     typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
     auto ld = [](const __amdgpu_buffer_rsrc_t &rs, int lane_off, int row_off) {

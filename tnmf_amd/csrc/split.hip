@@ -16,6 +16,9 @@ bool split_has_corr_W(const Geo &g, int dtype) {
     if (dtype != 0) return false;
     if (g.Dy == 1 || g.Ay == 1) return false;   // 1-D signals: other kernels
     if (g.Ax > 16 || g.Ay > 16 || g.Dx < 4) return false;   // (16-byte window loads need 4 columns)
+    // H / neg / pos of one sample are addressed through 32-bit buffer offsets (atom * plane bytes + ...): all the planes
+    // of a sample, rounded up to whole atom tiles, must stay below 2^31 bytes or the offsets wrap
+    if ((size_t)align_up((size_t)g.M, 32) * g.Hy * (size_t)(g.Hs > g.Hx ? g.Hs : g.Hx) * 4 >= ((size_t)1 << 31)) return false;
     const int nr4 = (g.Ax + 3) / 4;
 #define HAS(AY_, NR4_) \
     if (g.Ay == AY_ && nr4 == NR4_) return true;
