@@ -21,14 +21,20 @@ mini-batches of --batch-size (global batch = the union of the ranks' local batch
 way BASELINE.json words configs 4 and 5.  Same kernels, same work per step as a full-batch iteration.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel group (by time) of the main leg; average launch duration from HIP events recorded on the
-                launch stream inside the timed region, priced against WHAT IS EXECUTED: a group on the exact f32 matrix
-                cores as algorithmic FLOP of the direct formulation per launch against 157.3 TFLOP/s (f32 MFMA = f32
-                vector); a group on the split kernel (3 x bf16 operand splits) as the 6 bf16 MFMA products it issues
-                per algorithmic product against the dense bf16 peak (2500 TFLOP/s); a group on the FFT family as the
-                bytes that formulation must stream per launch against 8 TB/s HBM.
-                `traffic` = HBM bytes per launch from the committed PMC passes (profiles/rNN_traffic.json).
-                roofline_by_kernel holds the same entry for every group.
+  roofline      the dominant single KERNEL of the step (the fused H update: one kernel per launch, the longest single kernel
+                in profiles/rNN_rocprof_kernel_stats.csv at every BASELINE config), named as in the rocprof CSV; average
+                launch duration from HIP events recorded on the launch stream inside the timed region.  `achieved` =
+                SURVEY 8d's ALGORITHMIC flops (matrix-core kernels) or bytes (FFT-family kernels) of that primitive per
+                launch / that duration: alg_flops = 2 F (both correlations, F = 2 N C M prod(A) prod(D)), alg_bytes =
+                s (2 |H| + |V| + |R|) for the H half step; F and s (|H| + |R|) for a reconstruct; 2 F and
+                s (|H| + |V| + |R|) for the W gradient.  `peak`: 157.3 TFLOP/s for kernels on the exact f32 MFMA; for the
+                split kernel 2500 / 6 TFLOP/s -- the dense bf16 peak divided by the six bf16 products one float32-grade
+                product costs (so frac = executed-but-unpadded bf16 flops / 2500); 8000 GB/s for HBM-bound kernels.
+                Beside it: executed_flops (every MFMA the launch issues, tile padding included), formulation_stream_bytes
+                (what the FFT formulation must stream), frac_hbm_peak (alg_bytes side), and `traffic` = HBM bytes per
+                launch of that kernel from the committed PMC passes (profiles/rNN_traffic_config<c>.json), null if none.
+                roofline_by_kernel prices every kernel group the same way; iteration.traffic_measured sums the PMC
+                traffic of all kernels of a step.
   parity        the other half of BASELINE.json's metric: the same code path (same --path) run for 5 iterations from
                 the reference's seeded start (np.random.seed(42), H drawn before W) on the first `samples` samples of
                 the workload, against the float64 C oracle on the same samples: max |dW| / max |W|, max |dH| / max |H|,
@@ -103,20 +109,67 @@ def synth_V_on_device(cfg, n_local, seed, device):
     return out
 
 
-def measured_traffic(kernel_name, cfg_id, family):
-    """HBM bytes per launch of a kernel group from the committed PMC passes (newest profiles/rNN_traffic.json that has
-    the group on this family; config 3 only)."""
+# kernel group of the timeline -> kernel family -> (name of its main kernel as rocprof prints it, further kernels)
+GROUP_KERNELS = {
+    'update_H': {'split': ('k_split_corr_W', ()), 'mfma': ('k_mfma_corr_W', ()), 'generic': ('k_corr_W', ()),
+                 'fft': ('k_fft_rows_mu', ('k_fft_grad_H', 'k_fft_rows_fwd', 'k_fft_cols_fwd'))},
+    'reconstruct': {'fft': ('k_mix_reconstruct', ('k_fft_rows_fwd', 'k_fft_rows_inv', 'k_fft_contract_R',
+                                                   'k_spectral_contract_R', 'k_fft_cols_fwd', 'k_fft_cols_inv')),
+                    'mfma': ('k_mfma_reconstruct', ()), 'generic': ('k_reconstruct', ())},
+    'grad_W': {'fft': ('k_mix_grad_W', ('k_fft_grad_W', 'k_spectral_grad_W', 'k_fft_sum_groups', 'k_fft_rows_fwd')),
+               'mfma': ('k_mfma_corr_H', ('k_corr_H_finalize',)), 'generic': ('k_corr_H', ('k_corr_H_finalize',))},
+}
+
+
+def committed_profile(cfg_id, what):
+    """Newest committed profiles/rNN_<what>_config<c>.<ext> (config 3 also without the suffix)."""
     import glob
-    if cfg_id != 3:
+    pats = [f'r*_{what}_config{cfg_id}.*'] + ([f'r*_{what}.*'] if cfg_id == 3 else [])
+    found = sorted((f for p in pats for f in glob.glob(os.path.join(ROOT, 'profiles', p))),
+                   key=lambda f: os.path.basename(f)[:3], reverse=True)
+    return found[0] if found else None
+
+
+def measured_traffic(cfg_id):
+    """{'file', 'iteration_bytes', 'per_kernel': {rocprof kernel name: {...}}} of the committed PMC passes, or None."""
+    f = committed_profile(cfg_id, 'traffic')
+    if not f or not f.endswith('.json'):
         return None
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
-        try:
-            entry = json.load(open(f))['kernels'][kernel_name]
-            if entry.get('family', 'mfma') == family:
-                return entry['traffic_bytes']
-        except (KeyError, ValueError, OSError):
-            continue
-    return None
+    try:
+        d = json.load(open(f))
+        if 'per_kernel' not in d:
+            return None
+        d['file'] = os.path.relpath(f, ROOT)
+        return d
+    except (ValueError, OSError):
+        return None
+
+
+def kernel_traffic(traffic, substr):
+    """(rocprof name, bytes per launch) of the most expensive kernel whose name contains `substr`."""
+    if not traffic:
+        return None, None
+    hits = [(k, v) for k, v in traffic['per_kernel'].items() if '::' + substr in k]
+    if not hits:
+        return None, None
+    k, v = max(hits, key=lambda kv: kv[1]['bytes_per_iteration'])
+    return k, v['bytes_per_launch']
+
+
+def rocprof_average_ms(cfg_id, substr):
+    """Average duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary (ms), with the file."""
+    import csv
+    f = committed_profile(cfg_id, 'rocprof_kernel_stats')
+    if not f:
+        return None, None
+    try:
+        rows = [r for r in csv.DictReader(open(f)) if '::' + substr in r['Name']]
+    except (OSError, KeyError):
+        return None, None
+    if not rows:
+        return None, None
+    r = max(rows, key=lambda r: float(r['TotalDurationNs']))
+    return float(r['AverageNs']) * 1e-6, os.path.relpath(f, ROOT)
 
 
 def cpu_baseline(cfg, budget_s=20.0):
@@ -254,34 +307,58 @@ def main():
     batch_size_g = args.batch_size if args.batch_size else max(1, n_global // 4)
     launch_scale = 1.0 if args.algorithm == 'full' else min(1.0, -(-batch_size_g // world) / n_local)
 
+    v_bytes = 4.0 * n_local * cfg['C'] * float(np.prod(cfg['D']))   # |V| = |R|
+    traffic = measured_traffic(args.config) if not args.samples and args.algorithm == 'full' else None
+
+    def split_executed_flops():
+        """Every bf16 MFMA flop one launch of the split kernel issues (tile padding included): per 8 x 32-pixel tile,
+        atom tile and channel, 4 waves x KB k-blocks x 2 rows x (V, R) x 6 products of 32 x 32 x 16."""
+        ay, ax = cfg['A']
+        kb = (((ay + 1) // 2) * ((ax + 3) // 4) + 1) // 2
+        tiles = n_local * -(-Hs[0] // 8) * -(-Hs[1] // 32) * -(-cfg['M'] // 32) * cfg['C']
+        return launch_scale * tiles * 4 * kb * 4 * 6 * (2.0 * 32 * 32 * 16)
+
     def group_roofline(name, avg_ms, paths):
-        """Roofline entry of one kernel group: matrix-core groups against the f32 MFMA rate with the algorithmic flops of
-        the direct formulation, FFT-family groups against HBM with the streams that formulation must move per launch."""
+        """Roofline entry of one kernel group, priced with SURVEY 8d's ALGORITHMIC work of the primitive per launch:
+        matrix-core kernels by flops (f32 MFMA: 157.3 TFLOP/s; split kernel: the dense bf16 peak / 6 products per
+        float32-grade product), FFT-family kernels by bytes against HBM."""
         fam = paths.get(name)
-        flops = {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}.get(name)
-        if flops is None or not avg_ms:
+        alg_f = {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}.get(name)
+        if alg_f is None or not avg_ms:
             return None
-        flops *= launch_scale
+        alg_f *= launch_scale
+        alg_b = launch_scale * {'reconstruct': h_bytes + v_bytes, 'update_H': 2 * h_bytes + 2 * v_bytes,
+                                'grad_W': h_bytes + 2 * v_bytes}[name]
+        sec = avg_ms * 1e-3
+        main, _others = GROUP_KERNELS.get(name, {}).get(fam, (name, ()))
+        kname, kbytes = kernel_traffic(traffic, main)
+        r = {'kernel': kname or main, 'group': name, 'family': fam, 'avg_launch_ms': avg_ms,
+             'alg_flops': alg_f, 'alg_bytes': alg_b,
+             'alg_tflops': alg_f / sec / 1e12, 'alg_gbs': alg_b / sec / 1e9, 'frac_hbm_peak': alg_b / sec / 1e9 / PEAK_HBM_GBS,
+             'traffic': kbytes}
         if fam == 'split':
-            # what is executed: six bf16 MFMA products per algorithmic f32 product (3 x bf16 operand splits)
-            tf = 6 * flops / (avg_ms * 1e-3) / 1e12
-            rmw = launch_scale * (2 * h_bytes + 8.0 * n_local * cfg['C'] * float(np.prod(cfg['D']))) / (avg_ms * 1e-3) / 1e9
-            return {'kernel': name, 'family': fam, 'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': tf / PEAK_BF16_TFLOPS, 'flops_per_launch': 6 * flops,
-                    'avg_launch_ms': avg_ms, 'priced_as': 'bf16 MFMA flops executed = 6 x algorithmic (3 x bf16 splits)',
-                    'f32_equivalent_tflops': flops / (avg_ms * 1e-3) / 1e12,
-                    'hbm_gbs_alg': rmw, 'frac_hbm_peak': rmw / PEAK_HBM_GBS}
-        if fam == 'fft':
+            peak = PEAK_BF16_TFLOPS / 6.0
+            ex = split_executed_flops()
+            r.update({'bound': 'mfma', 'achieved': r['alg_tflops'], 'peak': peak, 'unit': 'TFLOP/s',
+                      'frac': r['alg_tflops'] / peak,
+                      'peak_basis': 'dense bf16 MFMA peak (2500 TFLOP/s) / 6 bf16 products per float32-grade product '
+                                    '(3 x bf16 operand splits)',
+                      'executed_flops': ex, 'executed_tflops': ex / sec / 1e12,
+                      'executed_frac_of_bf16_peak': ex / sec / 1e12 / PEAK_BF16_TFLOPS,
+                      'alg_frac_of_f32_peak': r['alg_tflops'] / PEAK_F32_TFLOPS})
+        elif fam == 'fft':
             hybrid = paths.get('update_H') != 'fft'     # H changes outside the family: its row spectra are redone
             streams = launch_scale * {'reconstruct': t_bytes + (0.5 * (h_bytes + t_bytes) if hybrid else 0.0),
                                       'update_H': 5 * t_bytes + 2 * h_bytes, 'grad_W': t_bytes}[name]
-            gbs = streams / (avg_ms * 1e-3) / 1e9
-            return {'kernel': name, 'family': fam, 'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': gbs / PEAK_HBM_GBS, 'bytes_per_launch': streams, 'avg_launch_ms': avg_ms,
-                    'direct_equivalent_tflops': flops / (avg_ms * 1e-3) / 1e12}
-        tf = flops / (avg_ms * 1e-3) / 1e12
-        return {'kernel': name, 'family': fam, 'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': tf / PEAK_F32_TFLOPS, 'flops_per_launch': flops, 'avg_launch_ms': avg_ms}
+            r.update({'bound': 'hbm', 'achieved': r['alg_gbs'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                      'frac': r['frac_hbm_peak'], 'formulation_stream_bytes': streams,
+                      'formulation_stream_gbs': streams / sec / 1e9,
+                      'note': 'a group of several kernels (row transforms, contraction, inverse rows): the group time '
+                              'prices the primitive; `traffic` is the main kernel alone'})
+        else:
+            r.update({'bound': 'mfma', 'achieved': r['alg_tflops'], 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                      'frac': r['alg_tflops'] / PEAK_F32_TFLOPS, 'executed_flops': alg_f})
+        return r
 
     batch_size = batch_size_g
 
@@ -402,11 +479,21 @@ def main():
         rl = {name: group_roofline(name, kernels[name]['avg_ms'], paths) for name in kernels}
         rl = {n: r for n, r in rl.items() if r}
         for n, r in rl.items():
-            kernels[n]['direct_equivalent_tflops'] = launch_scale * {'reconstruct': F, 'update_H': 2 * F, 'grad_W': 2 * F}[n] / (kernels[n]['avg_ms'] * 1e-3) / 1e12
-        dom = max(rl, key=lambda n: kernels[n]['total_ms'])
+            kernels[n]['direct_equivalent_tflops'] = r['alg_tflops']
+        # the dominant single kernel: the fused H update is ONE kernel per launch (plus a 5 us operand preparation) and
+        # the longest single kernel of the step at every BASELINE config (profiles/rNN_rocprof_kernel_stats*.csv); the
+        # FFT-family groups are several kernels each, none of them longer.  Under --path fft the H update is a group
+        # too: the group with the largest total time is reported then.
+        single = [n for n in rl if paths.get(n) in ('split', 'mfma', 'generic') and n == 'update_H']
+        dom = single[0] if single else max(rl, key=lambda n: kernels[n]['total_ms'])
         ms_per_step = elapsed / args.steps * 1e3
         roof = dict(rl[dom])
-        roof['traffic'] = measured_traffic(dom, args.config, paths.get(dom)) if not args.samples else None
+        roof['dominance'] = ('longest single kernel of the step' if single else
+                             'kernel group with the largest total time (every group is several kernels on this path)')
+        main_kernel = GROUP_KERNELS.get(dom, {}).get(paths.get(dom), (dom, ()))[0]
+        prof_ms, prof_file = rocprof_average_ms(args.config, main_kernel) if args.algorithm == 'full' and not args.samples else (None, None)
+        roof['rocprof_avg_launch_ms'] = prof_ms
+        roof['rocprof_file'] = prof_file
         line = {
             'metric': 'MU-iterations/sec', 'value': world * args.steps / elapsed, 'unit': 'MU-iterations/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -434,6 +521,10 @@ def main():
                 'direct_equivalent_tflops': 6 * F / (ms_per_step * 1e-3) / 1e12,
                 'hbm_gbs_alg': alg_bytes(cfg, n_local) / (ms_per_step * 1e-3) / 1e9,
                 'frac_hbm_peak': alg_bytes(cfg, n_local) / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                # HBM bytes of one step summed over every kernel, from the committed PMC passes of this configuration
+                'traffic_measured': traffic['iteration_bytes'] if traffic else None,
+                'traffic_over_bytes_alg': traffic['iteration_bytes'] / alg_bytes(cfg, n_local) if traffic else None,
+                'traffic_file': traffic['file'] if traffic else None,
             },
             'kernels': kernels,
             'roofline': roof,

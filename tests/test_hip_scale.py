@@ -280,6 +280,13 @@ def test_minibatch_slices_share_one_spectrum_cache(path):
     got = be.local_gradient_W(V, W, H, batches[1])
     gn, gp = orc.gradient_W(Vn, Wn, Hn, batches[1], 'c')
     assert relmax(got[0].cpu().numpy(), gn) < 4e-5 and relmax(got[1].cpu().numpy(), gp) < 4e-5
+    # the dictionary's spectra are kept between W updates as well: a torch-side write to W must be seen
+    W.mul_(1.5)
+    Wn = Wn * 1.5
+    be.fused_update_H(V, W, H, batches[0], sparsity=0., eps=1e-9)
+    on, op = orc.gradient_H(Vn, Wn, Hn, batches[0], 'c')
+    Hn[batches[0]] = Hn[batches[0]] * on / (op + 1e-9)
+    assert relmax(be.to_ndarray(H), Hn) < tol_H
 
 
 def test_reflect_mode_rejects_a_pad_as_long_as_the_row():

@@ -167,19 +167,23 @@ class HIP_Backend(Backend):
         base = Hs._base if Hs._base is not None else Hs
         return base, (base.data_ptr(), tuple(base.shape), base._version)
 
-    def _validate_H_cache(self, Hs: torch.Tensor) -> None:
+    def _validate_H_cache(self, Hs: torch.Tensor, W: Optional[torch.Tensor] = None) -> None:
+        """Before a fused call: drop what the library cached about H (and about the dictionary W, whose spectra it keeps
+        between W updates) unless both are the tensors, unwritten by torch, that the last fused call left behind."""
         c = self._cached_H
         if c is None:
             self._lib.tnmf_hip_ctx_invalidate(self._ctx)
             return
         base, key = self._h_key(Hs)
-        if c[0]() is not base or c[1] != key:
+        w_same = W is None or (c[2] is not None and c[2]() is W and c[3] == (W.data_ptr(), W._version))
+        if c[0]() is not base or c[1] != key or not w_same:
             self._lib.tnmf_hip_ctx_invalidate(self._ctx)
             self._cached_H = None
 
-    def _note_H_cache(self, Hs: torch.Tensor) -> None:
+    def _note_H_cache(self, Hs: torch.Tensor, W: Optional[torch.Tensor] = None) -> None:
         base, key = self._h_key(Hs)
-        self._cached_H = (weakref.ref(base), key)
+        self._cached_H = (weakref.ref(base), key, None if W is None else weakref.ref(W),
+                          None if W is None else (W.data_ptr(), W._version))
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
@@ -394,7 +398,7 @@ class HIP_Backend(Backend):
         self._check_W(W)
         self._check_H(Hs, W.shape[0])
         if self._mode == 0:
-            self._validate_H_cache(Hs)
+            self._validate_H_cache(Hs, W)
         Hs = self._pad(Hs)
         negpos = torch.empty_like(self._negpos)
         Rs = self._R_scratch[ls] if Hs.shape[0] else None
@@ -418,7 +422,7 @@ class HIP_Backend(Backend):
         if copied:
             self._foreign_H()   # the spectra the library may have kept belong to a temporary
         elif self._mode == 0 and Hs.shape[0]:
-            self._note_H_cache(Hs)
+            self._note_H_cache(Hs, W)
         return negpos
 
     def reconstruction_gradient_W(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone):
@@ -512,7 +516,7 @@ class HIP_Backend(Backend):
             self.multiplicative_update(Hs, neg, pos, eps + (sparsity if sparsity > 0 else 0.))
             return
         Rs = self._R_scratch[ls]
-        self._validate_H_cache(Hs)
+        self._validate_H_cache(Hs, W)
 
         def run(Hc, ld):
             g = self._geom(Hc.shape[0], W.shape[0], ld)
@@ -532,7 +536,7 @@ class HIP_Backend(Backend):
         if self._call_H(Hs, True, run):
             self._foreign_H()   # the library updated (and kept spectra of) a temporary copy
         else:
-            self._note_H_cache(Hs)
+            self._note_H_cache(Hs, W)
 
     def apply_W(self, W: torch.Tensor, negpos: torch.Tensor, eps: float = 1e-9) -> None:
         """W = W * neg / (pos + eps), then normalise over the atom axes (TransformInvariantNMF.py:232-238)."""

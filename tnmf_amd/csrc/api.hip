@@ -423,6 +423,7 @@ int tnmf_hip_mu_update(tnmf_hip_ctx *ctx, int dtype, void *arr, const void *neg,
 int tnmf_hip_normalize_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W, void *stream) {
     ENTER(ctx, geom);
     if (!W) return TNMF_E_NULL;
+    fft_invalidate_W(ctx);
     return launch_apply_normalize_W(g, dtype, W, nullptr, nullptr, 0.0, false, s);
 }
 
@@ -514,6 +515,7 @@ int tnmf_hip_apply_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W_inout
                      void *stream) {
     ENTER(ctx, geom);
     if (!W_inout || !negpos) return TNMF_E_NULL;
+    fft_invalidate_W(ctx);
     char *np = static_cast<char *>(negpos);
     const size_t wbytes = (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype);
     return launch_apply_normalize_W(g, dtype, W_inout, np, np + wbytes, eps, true, s);

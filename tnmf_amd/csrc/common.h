@@ -41,6 +41,13 @@ struct FftState {
     std::vector<unsigned char> SH_ok;   // their column transforms (full spectra) as well
     std::vector<unsigned char> V_ok;    // the row spectra of V[n]
     std::vector<unsigned char> SV_ok;   // their full spectra as well
+    // the spectra of the dictionary used by reconstruct (row spectra TWr for the mixed kernels, full spectra SW
+    // otherwise): W stays the same between the W updates of a mini-batch schedule, every batch reuses them.  Dropped by
+    // every entry point that writes W (apply_W, normalize_W, mu_update) and by tnmf_hip_ctx_invalidate.
+    const void *W_owner = nullptr;
+    bool W_ok = false;
+    Geo W_geo = {};
+    int W_dtype = 0;
     // row-transform passes over H / V: run, and skipped because the cache held every sample of the call
     // (tnmf_hip_ctx_cache_counters)
     unsigned long long h_runs = 0, h_hits = 0, v_runs = 0, v_hits = 0;

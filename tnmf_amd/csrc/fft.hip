@@ -48,7 +48,7 @@ struct Lay {
     int Ly, Lx, KX, KXP, ngroups, nper, chunk, mgroups, mper;
     fft_run_fn rowf, colf;
     size_t csz;  // bytes of one complex element
-    size_t T, SH, Tn, Tp, SV, SR, Ts, VT, RT, SW, SWf, TW, Wt, Gn, Gp, Gs, Wo, total, total_no_window;
+    size_t T, SH, Tn, Tp, SV, SR, Ts, VT, RT, SW, SWf, TW, TWr, Wt, Gn, Gp, Gs, Wo, total, total_no_window;
     size_t sT, sSH, sS, sD;   // bytes per sample of T, SH, SV | SR, Ts | VT | RT
     bool resident;   // full spectra of H are kept (SH): the contractions stream them instead of transforming tiles
 };
@@ -118,6 +118,7 @@ bool make_layout(const Geo &gfull, const Geo &g, int dtype, Lay *l) {
     l->SW = take(nSW);
     l->SWf = take(nSW);
     l->TW = take((size_t)2 * g.M * g.C * g.Ay * kxp * c);
+    l->TWr = take((size_t)g.M * g.C * g.Ay * kxp * c);   // row spectra of W for the mixed reconstruct (kept: FftState::W_ok)
     l->Wt = take((size_t)2 * g.M * g.C * g.Ay * g.Ax * (c / 2));
     // partial W-gradient spectra: [groups][M*C][Ly][KXP] for the column-transform kernel, [<= kMixMaxGroups groups]
     // [M*C][Ay][KXP] for the mixed kernel
@@ -135,6 +136,7 @@ bool make_layout(const Geo &gfull, const Geo &g, int dtype, Lay *l) {
 }
 
 void clear_flags(FftState &f) {
+    f.W_ok = false;
     std::fill(f.T_ok.begin(), f.T_ok.end(), 0);
     std::fill(f.SH_ok.begin(), f.SH_ok.end(), 0);
     std::fill(f.V_ok.begin(), f.V_ok.end(), 0);
@@ -551,6 +553,8 @@ void fft_invalidate_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H)
 
 void fft_invalidate(tnmf_hip_ctx *ctx) { clear_flags(ctx->fft); }
 
+void fft_invalidate_W(tnmf_hip_ctx *ctx) { ctx->fft.W_ok = false; }
+
 int fft_reserve(tnmf_hip_ctx *ctx, const Geo &g, int dtype, bool with_window) {
     Lay l;
     ctx->fft.failed_bytes = 0;   // an explicit request: try again even if this size was refused before
@@ -574,13 +578,31 @@ int fft_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, c
     CHECK(prepare(ctx, g, dtype, H, nullptr, &c));
     const Lay &l = c.l;
     CHECK(rows_of_H(ctx, g, c, dtype, H, s));
+    FftState &f = ctx->fft;
+    // the spectra of W this primitive needs are kept while W stays the same (mini-batch schedules: one W per epoch)
+    const bool w_hit = f.cache_enabled && f.W_ok && f.W_owner == W && f.W_dtype == dtype && same_shape(f.W_geo, g) &&
+                       (c.sl.cached || f.W_geo.N == g.N);   // (same layout: a slice of the binding, or the same call shape)
+    auto w_mark = [&]() {
+        f.W_ok = f.cache_enabled;
+        f.W_owner = W;
+        f.W_geo = g;
+        f.W_dtype = dtype;
+    };
     if (use_mixed(g, dtype, false)) {
         // transform along x only; the atom rows are contracted directly (fft_mixed.hip)
-        CHECK(scaled_W(ctx, g, l, dtype, W, 1.0 / l.Lx, s));
-        CHECK(forward_rows(g, l, dtype, at(ctx, l.Wt), g.M * g.C, g.Ay, g.Ax, at(ctx, l.TW), s));
-        CHECK(mixed_reconstruct(g, c.T, at(ctx, l.TW), c.Ts, l.KX, l.KXP, s));
+        if (!w_hit) {
+            f.W_ok = false;
+            CHECK(scaled_W(ctx, g, l, dtype, W, 1.0 / l.Lx, s));
+            CHECK(forward_rows(g, l, dtype, at(ctx, l.Wt), g.M * g.C, g.Ay, g.Ax, at(ctx, l.TWr), s));
+            w_mark();
+        }
+        CHECK(mixed_reconstruct(g, c.T, at(ctx, l.TWr), c.Ts, l.KX, l.KXP, s));
     } else {
-        CHECK(spectra_W(ctx, g, l, dtype, W, true, false, s));
+        if (!w_hit) {
+            f.W_ok = false;
+            CHECK(spectra_W(ctx, g, l, dtype, W, true, false, s));
+            w_mark();
+        }
         if (use_resident(l)) {
             CHECK(spectra_of_H(ctx, g, c, dtype, H, s));
             CHECK(spectral_contract_R(g, dtype, c.SH, at(ctx, l.SW), c.SR, l.Ly, l.KX, l.KXP, s));
@@ -756,10 +778,20 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
         TNMF_LAUNCH_CHECK();
     } else {
         CHECK(forward_planes(g, l, dtype, R, g.N * g.C, g.Dy, g.Dx, c.Ts, c.SR, s));
+        int ngroups = l.ngroups;
         if (use_resident(l)) {
             CHECK(spectra_of_H(ctx, g, c, dtype, H, s));
-            CHECK(spectral_grad_W(g, dtype, c.SH, c.SV, c.SR, at(ctx, l.Gn), at(ctx, l.Gp), l.Ly, l.KX, l.KXP, l.ngroups,
-                                  l.nper, s));
+            // Sample groups of the streaming kernel: every group writes (and the sum reads back) a full set of partial
+            // gradient spectra -- 2 x 35 MB per group at config 4, as much as the activations of 6 samples -- so only
+            // as many as it takes to fill the chip about twice with (atom quads) x (f blocks) x (channel groups)
+            // workgroups of four waves
+            const long blocks = (long)cdiv(g.M, 4) * (((long)l.Ly * l.KXP + 255) / 256) * cdiv(g.C, 4);
+            int ng = (int)((8L * ctx->num_cu + blocks - 1) / blocks);
+            ng = ng < 1 ? 1 : (ng > l.ngroups ? l.ngroups : ng);
+            const int nper = cdiv(g.N, ng);
+            ngroups = cdiv(g.N, nper);
+            CHECK(spectral_grad_W(g, dtype, c.SH, c.SV, c.SR, at(ctx, l.Gn), at(ctx, l.Gp), l.Ly, l.KX, l.KXP, ngroups,
+                                  nper, s));
         } else {
             FftArgs a = base_args(g, l);
             a.src0 = c.T;
@@ -781,11 +813,11 @@ int fft_grad_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const 
             if (dtype == 0)
                 hipLaunchKernelGGL(k_fft_sum_groups<float>, grid, dim3(64), 0, s, (const cplx<float> *)at(ctx, l.Gn),
                                    (const cplx<float> *)at(ctx, l.Gp), (cplx<float> *)out, (cplx<float> *)(out + sbytes),
-                                   count, l.ngroups, scale);
+                                   count, ngroups, scale);
             else
                 hipLaunchKernelGGL(k_fft_sum_groups<double>, grid, dim3(64), 0, s, (const cplx<double> *)at(ctx, l.Gn),
                                    (const cplx<double> *)at(ctx, l.Gp), (cplx<double> *)out,
-                                   (cplx<double> *)(out + sbytes), count, l.ngroups, scale);
+                                   (cplx<double> *)(out + sbytes), count, ngroups, scale);
             TNMF_LAUNCH_CHECK();
         }
         FftArgs b = base_args(g, l);
