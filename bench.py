@@ -240,6 +240,8 @@ def main():
                     help='full: full-batch MU iterations; cyclic: Cyclic-MU epochs over mini-batches (configs 4, 5)')
     ap.add_argument('--batch-size', type=int, default=None, help='global mini-batch size of --algorithm cyclic '
                     '(default: a quarter of the global sample count)')
+    ap.add_argument('--reduce', default='all_reduce', choices=['all_reduce', 'ordered'],
+                    help="cross-rank sum of the W gradient: one RCCL all-reduce, or all-gather + fixed rank-order sum")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fft-variant', action='store_true', help='skip the extra timed legs on the other kernel families')
     ap.add_argument('--no-parity', action='store_true', help='skip the parity leg against the float64 oracle')
@@ -368,7 +370,7 @@ def main():
         np.random.seed(42)             # same W on every rank
         torch.cuda.manual_seed(4242 + rank)
         model = TransformInvariantNMF(n_atoms=cfg['M'], atom_shape=tuple(cfg['A']), backend='hip', device=device,
-                                      path=path, init='device', process_group=pg, split=split)
+                                      path=path, init='device', process_group=pg, split=split, reduce=args.reduce)
         model._initialize_matrices(V, keep_W=False)
         b = model._backend
         if args.algorithm == 'cyclic':
@@ -432,6 +434,8 @@ def main():
                 'value': args.steps / el2, 'unit': 'MU-iterations/sec', 'ms_per_step': el2 / args.steps * 1e3,
                 'path': vpath, 'split': vsplit, 'kernel_families': paths2, 'kernels_ms': ms2,
                 'what': 'same data, same start, same iteration count, every kernel group forced onto this family',
+                'parity_scope': ('W and energy only (float32 transform noise in H: not a parity-grade H update)'
+                                 if vpath == 'fft' else 'W, H and energy'),
                 'W_max_rel_diff_vs_main': float(np.abs(m2.W - W_main).max() / np.abs(W_main).max()),
                 'energy_after_run': m2._energy_function(),
                 'speed_relative_to_main': (args.steps / el2) / (world * args.steps / elapsed),
@@ -510,7 +514,8 @@ def main():
                 'h_update_arithmetic': ('3 x bf16 operand splits on the bf16 matrix cores (float32-grade; parity '
                                         'object and exact_f32_variant beside it)' if 'split' in fams else
                                         'exact f32' if paths.get('update_H') in ('mfma', 'generic') else 'fft'),
-                'parallelism': f'sample-sharded x{world}, all-reduce of W num/den per iteration' if world > 1 else 'single GPU',
+                'parallelism': (f'sample-sharded x{world}, ' + ('all-reduce' if args.reduce == 'all_reduce' else
+                                'all-gather + rank-order sum') + ' of W num/den per step') if world > 1 else 'single GPU',
                 'value_definition': 'shard-iterations completed by all ranks / max-over-ranks wall time',
                 'energy_after_run': energy,
             },

@@ -63,7 +63,10 @@ typedef struct {
 /* Kernel family selection (tnmf_hip_ctx_set_path): AUTO picks the MFMA kernels where the shape allows and, for float32
  * problems with at least 2^19 activation entries, the HYBRID dispatch described below.  FFT is the
  * frequency-domain formulation (the algorithm of the reference's default backend, tnmf/backends/NumPy_FFT.py:16-40):
- * float32 2-D problems with shift shapes up to 576, float64 up to 288. */
+ * float32 2-D problems with shift shapes up to 576, float64 up to 288.  In float32 FFT is a W-ONLY path: the dictionary
+ * and the energy of a fit stay within 1e-5 of a float64 reference, the activations do not (every gradient entry carries
+ * ~1e-7 of the LARGEST entry as absolute transform error, and the H update divides two gradients); callers who need H at
+ * float32 grade use AUTO / HYBRID, whose H update runs on the direct kernels. */
 enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_FFT = 3, TNMF_PATH_HYBRID = 4,
        TNMF_PATH_SPLIT = 5 };
 /* HYBRID: reconstruct and the W gradient on the FFT family (their float32 transform error is benign: R has no small
@@ -181,6 +184,14 @@ int tnmf_hip_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *
  *   R_scratch / r_is_valid as for tnmf_hip_update_H. */
 int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,
                           void *R_scratch, int r_is_valid, void *negpos, void *stream);
+
+/* Deterministic cross-rank reduction of the [neg | pos] buffer ("all-gather ... then sum in rank order"):
+ *   out[i] = ((parts[0][i] + parts[1][i]) + parts[2][i]) + ...   for the n_parts buffers of n_elems elements that the
+ * caller gathered one behind the other (rank order), in the element type.  Every rank that runs it on the same gathered
+ * buffer gets the same bits, whatever protocol the collective library would have picked for an all-reduce.  The gather
+ * itself is the caller's (torch.distributed.all_gather_into_tensor over RCCL in tnmf_amd/backends/HIP.py). */
+int tnmf_hip_sum_parts(tnmf_hip_ctx *ctx, int dtype, const void *parts, int n_parts, size_t n_elems, void *out,
+                       void *stream);
 
 /* Rest of _update_W (TransformInvariantNMF.py:232-238,244): W = W * neg / (pos + eps); W /= sum over atom axes.
  * `pos` is left incremented by eps, like the reference's in-place `pos += eps`. */

@@ -1,7 +1,7 @@
 """
 TEST-ONLY in-process collective: lets several HIP_Backend objects act as the ranks of one sample-sharded job inside ONE
 process on ONE GPU (each rank on its own Python thread, its own library context).  It implements the small interface
-HIP_Backend accepts in place of a torch.distributed group -- ``rank``, ``world_size``, ``all_reduce_sum(tensor)`` -- with
+HIP_Backend accepts in place of a torch.distributed group -- ``rank``, ``world_size``, ``all_reduce_sum(tensor)``, ``all_gather(tensor)`` -- with
 a fixed-rank-order sum, so the ranks' results are bit-identical to each other like RCCL's are.
 """
 import threading
@@ -35,6 +35,18 @@ class LocalRank:
         if self.rank == 0:
             g.calls += 1
         g._barrier.wait()                    # nobody overwrites a slot that is still being read
+
+
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """The ranks' tensors one behind the other, in rank order."""
+        g = self.group
+        g._slots[self.rank] = t.detach().clone()
+        g._barrier.wait()
+        out = torch.stack([g._slots[r] for r in range(g.world_size)])
+        if self.rank == 0:
+            g.calls += 1
+        g._barrier.wait()
+        return out
 
 
 def run_ranks(world_size: int, fn):

@@ -87,3 +87,21 @@ def test_two_ranks_match_single_process(tmp_path, mode):
     np.testing.assert_allclose(np.concatenate([r0['H'], r1['H']]), ref.H, rtol=1e-12)
     assert np.isclose(float(r0['E']), ref._energy_function(), rtol=1e-12)
     assert float(r0['E']) == float(r1['E'])
+
+
+def _gather_worker(rank, world, port, out):
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    try:
+        t = torch.arange(6, dtype=torch.float32).reshape(2, 3) + 10 * rank
+        parts = sharding.all_gather(t, dist.group.WORLD)
+        np.save(os.path.join(out, f'gather{rank}.npy'), parts.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_is_in_rank_order(tmp_path):
+    """The gather of the 'ordered' reduction (HIP_Backend(reduce='ordered')): [world, *shape], rank r at index r."""
+    mp.spawn(_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = np.stack([np.arange(6, dtype=np.float32).reshape(2, 3) + 10 * r for r in range(2)])
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f'gather{r}.npy'), want)

@@ -62,7 +62,10 @@ class HIP_Backend(Backend):
            (``'auto'`` = the fastest dispatch that keeps W and H within 1e-5 of the float64 reference; ``'mfma'`` = direct
            kernels on the exact f32-input MFMA; ``'split'`` = direct kernels with the H update on the bf16 matrix
            cores through exact 3 x bf16 operand splits; ``'fft'`` = frequency-domain formulation, the algorithm of the
-           reference's default backend; ``'hybrid'`` = FFT family for reconstruct and the W gradient, direct H update)
+           reference's default backend -- **W-only in float32**: W and the energy stay within 1e-5 of the float64
+           reference, the activations do NOT (float32 transform noise in the quotient of two small gradients; measured
+           up to 2e-3 of max|H| after 5 iterations); in float64 everything is within 1e-10; ``'hybrid'`` = FFT family
+           for reconstruct and the W gradient, direct H update)
     split : ``True`` (default) lets ``'auto'`` / ``'hybrid'`` run the H update on the bf16 matrix cores (3 x bf16 splits,
            float32-grade); ``False`` keeps it on the exact f32-input MFMA
     init : ``'reference'`` draws H then W from the global legacy NumPy RNG exactly like the reference
@@ -72,10 +75,14 @@ class HIP_Backend(Backend):
            an in-process one to run two ranks on one GPU).  With a group the sample axis is sharded in contiguous blocks
            over the ranks: this rank keeps V[n0:n1] and H[n0:n1], the W-gradient numerator/denominator is all-reduced
            (sum) before it is returned, the energy likewise.
+    reduce : ``'all_reduce'`` (one RCCL all-reduce; the order of the additions is RCCL's choice of protocol) or
+           ``'ordered'``: all-gather of the ranks' [neg | pos] buffers, then their sum in rank order by a library kernel --
+           bit-identical on every rank and from run to run.  The buffers are 37-393 KB: either way the
+           exchange is latency-bound.
     """
 
     def __init__(self, reconstruction_mode: str = 'valid', device=None, path: str = 'auto', init: str = 'reference',
-                 process_group=None, split: bool = True):
+                 process_group=None, split: bool = True, reduce: str = 'all_reduce'):
         if reconstruction_mode not in _lib.MODES:
             raise ValueError(f'Unsupported reconstruction mode "{reconstruction_mode}". '
                              f'Please choose "valid", "full", "circular", or "reflect".')
@@ -89,7 +96,10 @@ class HIP_Backend(Backend):
         self._device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         if self._device.index is None:
             self._device = torch.device('cuda', torch.cuda.current_device())
+        if reduce not in ('all_reduce', 'ordered'):
+            raise ValueError(f'reduce must be "all_reduce" or "ordered", not {reduce!r}')
         self._init_mode = init
+        self._reduce = reduce
         self._ctx = ctypes.c_void_p()
         _lib.check(self._lib.tnmf_hip_ctx_create(self._device.index, ctypes.byref(self._ctx)), 'tnmf_hip_ctx_create')
         _lib.check(self._lib.tnmf_hip_ctx_set_path(self._ctx, _lib.PATHS[path]), 'tnmf_hip_ctx_set_path')
@@ -307,6 +317,17 @@ class HIP_Backend(Backend):
         return G
 
     def _all_reduce(self, t: torch.Tensor) -> None:
+        if self._world > 1 and self._reduce == 'ordered':
+            # fixed-order reduction: gather every rank's buffer, then add them up in rank order on the device
+            # (tnmf_hip_sum_parts) -- the same bits on every rank and from run to run, whatever RCCL protocol an all-reduce
+            # of this size would have used
+            parts = (self._collective.all_gather(t) if self._collective is not None
+                     else sharding.all_gather(t, self._group))
+            assert t.is_contiguous() and parts.is_contiguous() and parts.shape[0] == self._world
+            code = _DTYPES[np.dtype(str(t.dtype).replace('torch.', ''))][1]
+            _lib.check(self._lib.tnmf_hip_sum_parts(self._ctx, code, _ptr(parts), self._world, t.numel(), _ptr(t),
+                                                    self._stream()), 'tnmf_hip_sum_parts')
+            return
         if self._collective is not None:
             self._collective.all_reduce_sum(t)
         else:

@@ -511,6 +511,16 @@ int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
     return do_corr_H(ctx, g, dtype, sc, V, Rs, H, np, np + wbytes, s);
 }
 
+int tnmf_hip_sum_parts(tnmf_hip_ctx *ctx, int dtype, const void *parts, int n_parts, size_t n_elems, void *out,
+                       void *stream) {
+    if (!ctx) return TNMF_E_NULL;
+    if (dtype != 0 && dtype != 1) return TNMF_E_DTYPE;
+    if (n_parts < 1) return TNMF_E_GEOM;
+    if (n_elems > 0 && (!parts || !out)) return TNMF_E_NULL;
+    TNMF_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_sum_parts(ctx, dtype, parts, n_parts, n_elems, out, static_cast<hipStream_t>(stream));
+}
+
 int tnmf_hip_apply_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W_inout, void *negpos, double eps,
                      void *stream) {
     ENTER(ctx, geom);

@@ -19,6 +19,8 @@ int finalize_corr_H(const Geo &g, int dtype, const double *partials, int P, void
 
 int launch_mu_update(const tnmf_hip_ctx *ctx, int dtype, void *arr, const void *neg, void *pos, double reg, size_t n,
                      hipStream_t s);
+int launch_sum_parts(const tnmf_hip_ctx *ctx, int dtype, const void *parts, int n_parts, size_t n, void *out,
+                     hipStream_t s);
 int launch_apply_normalize_W(const Geo &g, int dtype, void *W, const void *neg, void *pos, double eps, bool apply,
                              hipStream_t s);
 int launch_half_sqdiff(const tnmf_hip_ctx *ctx, int dtype, const void *V, const void *R, size_t n, double *partials,

@@ -302,6 +302,17 @@ __global__ void k_mu_update(T *__restrict__ arr, const T *__restrict__ neg, T *_
     }
 }
 
+// out[i] = ((parts[0][i] + parts[1][i]) + parts[2][i]) + ...: the sum of `n_parts` buffers in their order, in T
+template <typename T>
+__global__ void k_sum_parts(const T *__restrict__ parts, int n_parts, size_t n, T *__restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T acc = parts[i];
+        for (int r = 1; r < n_parts; ++r) acc = acc + parts[(size_t)r * n + i];
+        out[i] = acc;
+    }
+}
+
 template <typename T>
 __device__ double block_sum(double v, double *sh) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -496,6 +507,19 @@ int launch_mu_update(const tnmf_hip_ctx *ctx, int dtype, void *arr, const void *
     else
         hipLaunchKernelGGL(k_mu_update<double>, dim3(grid), dim3(kBlock), 0, s, (double *)arr, (const double *)neg,
                            (double *)pos, reg, n);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int launch_sum_parts(const tnmf_hip_ctx *ctx, int dtype, const void *parts, int n_parts, size_t n, void *out,
+                     hipStream_t s) {
+    if (n == 0) return TNMF_OK;
+    const int grid = grid_for(n, ctx);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_sum_parts<float>, dim3(grid), dim3(kBlock), 0, s, (const float *)parts, n_parts, n, (float *)out);
+    else
+        hipLaunchKernelGGL(k_sum_parts<double>, dim3(grid), dim3(kBlock), 0, s, (const double *)parts, n_parts, n,
+                           (double *)out);
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
 }

@@ -63,3 +63,14 @@ def all_reduce_sum(tensor, group) -> None:
     import torch.distributed as dist
     if dist.get_world_size(group) > 1:
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+
+
+def all_gather(tensor, group):
+    """The ranks' tensors one behind the other, [world, *tensor.shape], in rank order (RCCL / gloo all-gather)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    flat = tensor.contiguous().reshape(-1)
+    out = torch.empty(world * flat.numel(), dtype=tensor.dtype, device=tensor.device)
+    dist.all_gather_into_tensor(out, flat, group=group)   # (flat on both sides: gloo insists on matching ranks)
+    return out.reshape((world,) + tuple(tensor.shape))
