@@ -179,6 +179,21 @@ int tnmf_hip_fold_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, cons
 int tnmf_hip_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, void *H_inout,
                       void *R_scratch, int r_is_valid, double eps, double sparsity, void *stream);
 
+/* TransformInvariantNMF._update_H in full (TransformInvariantNMF.py:246-271), for every reconstruction mode:
+ *   G   = kernel0 (*) kernel1 (*) H  along the shift axes, zeros outside (Backend.convolve_multi_1d, _NumPyBackend.py:56-64)
+ *   pos += inhibition * (G - H) + cross_inhibition / (M - 1) * (sum over atoms of G - G)            (:256-269)
+ *   H  *= neg / (pos + eps + sparsity)
+ * kernel0 / kernel1: HOST pointers to the odd-length 1-D kernels of the shift axes (ndim == 1: kernel0 only), ignored when
+ * both strengths are 0.  mode == TNMF_MODE_VALID: H as for tnmf_hip_update_H (row stride honoured); the lateral terms are
+ * computed by one kernel and enter the epilogue of the fused update (split kernel on row-padded H, generic kernels) or,
+ * for the other families, one update kernel behind the unfused gradient.  Other modes: H is C-contiguous with the mode's
+ * shift shape; the library pads it (work arrays of its own), runs the 'valid' kernels and applies fold + update in one
+ * kernel.  R_scratch: device buffer [N,C,*D] or NULL. */
+int tnmf_hip_update_H_ex(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *V, const void *W,
+                         void *H_inout, void *R_scratch, double eps, double sparsity, double inhibition,
+                         double cross_inhibition, const double *kernel0, int len0, const double *kernel1, int len1,
+                         void *stream);
+
 /* Local part of TransformInvariantNMF._update_W (TransformInvariantNMF.py:240-241 / :444-448):
  *   negpos[0] = neg_W, negpos[1] = pos_W as one contiguous [2,M,C,*A] buffer (what the all-reduce carries).
  *   R_scratch / r_is_valid as for tnmf_hip_update_H. */

@@ -96,6 +96,14 @@ class OracleBackend(Backend):
     def _fused_update_W(self, V, W, H, s=sliceNone, eps=1e-9):
         self._apply_W(W, self._reduce(self._local_gradient_W(V, W, H, s)), eps)
 
-    def _fused_update_H(self, V, W, H, s=sliceNone, sparsity=0., eps=1e-9):
+    def _fused_update_H(self, V, W, H, s=sliceNone, sparsity=0., eps=1e-9, inhibition=0., cross_inhibition=0.,
+                        inhibition_kernels=None):
         neg, pos = orc.gradient_H(self._V_local, W, H, s, self.impl)
+        if inhibition > 0 or cross_inhibition > 0:      # the reference's lines, TransformInvariantNMF.py:253-269
+            Hs = H[s]
+            g = orc.convolve_multi_1d(Hs, inhibition_kernels, tuple(range(-len(self.atom_shape), 0)))
+            if inhibition > 0:
+                pos += inhibition * (g - Hs)
+            if cross_inhibition > 0:
+                pos += cross_inhibition / (H.shape[1] - 1) * (g.sum(axis=1, keepdims=True) - g)
         orc.multiplicative_update(H[s], neg, pos, eps, sparsity)

@@ -556,3 +556,51 @@ def test_front_end_branches_on_row_padded_activations(kw):
     gap = abs(nmf._energy_function() - ref.energy()) / ref.energy()
     print(f'{kw}: dW={dW:.2e} dH={dH:.2e} gap={gap:.2e}')
     assert dW < 1e-5 and dH < 2e-5 and gap < 1e-5, (dW, dH, gap)
+
+
+@pytest.mark.parametrize('path,mode,lateral', [
+    ('auto', 'valid', True),        # split kernel with the extra-term epilogue (row-padded activations)
+    ('mfma', 'valid', True),        # f32 MFMA family: unfused gradient + one update kernel
+    ('generic', 'valid', True),     # generic fused kernel with the extra term
+    ('fft', 'valid', True),         # FFT family: unfused gradient + one update kernel
+    ('auto', 'circular', True), ('auto', 'reflect', False), ('auto', 'full', True),
+], ids=lambda v: str(v))
+def test_lateral_terms_and_modes_run_inside_the_library(path, mode, lateral):
+    """TransformInvariantNMF._update_H in full (reference :246-271) through tnmf_hip_update_H_ex: lateral inhibition and
+    cross-atom inhibition as an extra term of the fused update's denominator, the reconstruction modes with pad, gradient,
+    fold and update as kernels of the library -- float32, against the float64 oracle's front end."""
+    oracle_threads()
+    N, C, D, M, A = 4, 1, (96, 80), 32, (12, 12)
+    V = planted_V(N, C, D, M, A, seed=13)
+    kw = dict(n_iterations=3, sparsity_H=0.02)
+    if lateral:
+        kw.update(inhibition_strength=0.1, cross_atom_inhibition_strength=0.05)
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=M, atom_shape=A, backend='hip', path=path, reconstruction_mode=mode,
+                                inhibition_range=(3, 5))
+    calls = []
+    inner = nmf._backend._lib.tnmf_hip_update_H_ex
+
+    class Spy:   # (ctypes function objects cannot be patched in place)
+        def __getattr__(self, name):
+            if name == 'tnmf_hip_update_H_ex':
+                def counted(*a):
+                    calls.append(1)
+                    return inner(*a)
+                return counted
+            return getattr(lib, name)
+
+    lib = nmf._backend._lib
+    nmf._backend._lib = Spy()
+    nmf.fit(V, progress_callback=lambda *_: True, **kw)
+    nmf._backend._lib = lib
+    assert len(calls) == 3, 'the H half steps did not go through tnmf_hip_update_H_ex'
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c', reconstruction_mode=mode, inhibition_range=(3, 5))
+    ref.fit(V.astype(np.float64), **kw)
+    dW, dH = relmax(nmf.W, ref.W), relmax(nmf.H, ref.H)
+    gap = abs(nmf._energy_function() - ref.energy()) / ref.energy()
+    print(f'{path} {mode} lateral={lateral}: dW={dW:.2e} dH={dH:.2e} gap={gap:.2e}')
+    assert dW < 1e-5 and gap < 1e-5, (dW, dH, gap)
+    if path != 'fft':        # (path='fft' makes no parity claim on H in float32)
+        assert dH < 1e-5, dH

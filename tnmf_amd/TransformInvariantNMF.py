@@ -157,8 +157,12 @@ class TransformInvariantNMF:
     def _update_H(self, s: slice = sliceNone, sparsity: float = 0., inhibition: float = 0., cross_inhibition: float = 0.):
         lateral = inhibition > 0 or cross_inhibition > 0
         fused = self._fused('fused_update_H')
-        if fused is not None and not lateral:
-            fused(self._V, self._W, self._H, s, sparsity=sparsity, eps=self.eps)
+        if fused is not None:
+            if lateral:
+                fused(self._V, self._W, self._H, s, sparsity=sparsity, eps=self.eps, inhibition=inhibition,
+                      cross_inhibition=cross_inhibition, inhibition_kernels=self._inhibition_kernels_1D)
+            else:
+                fused(self._V, self._W, self._H, s, sparsity=sparsity, eps=self.eps)
             return
         neg, pos = self._backend.reconstruction_gradient_H(self._V, self._W, self._H, s)
         Hs = self._H[s]

@@ -523,18 +523,44 @@ class HIP_Backend(Backend):
             arr.copy_(flat)
 
     def fused_update_H(self, V, W: torch.Tensor, H: torch.Tensor, s: slice = sliceNone, sparsity: float = 0.,
-                       eps: float = 1e-9) -> None:
-        """One H half step without inhibition, in place (reference: TransformInvariantNMF.py:246-250,271)."""
+                       eps: float = 1e-9, inhibition: float = 0., cross_inhibition: float = 0.,
+                       inhibition_kernels: Optional[Sequence[np.ndarray]] = None) -> None:
+        """One H half step, in place (reference: TransformInvariantNMF.py:246-271): 'valid' mode without lateral terms on
+        the fused kernels (tnmf_hip_update_H); with lateral inhibition / cross-atom inhibition and for the other
+        reconstruction modes through tnmf_hip_update_H_ex -- the separable convolution, the lateral terms, the pad, the
+        fold and the update all run as kernels of the library."""
         ls = self._local(s)
         Hs, Vs = H[ls], self._V_dev[ls]
         if Hs.shape[0] == 0:
             return
         self._check_W(W)
         self._check_H(Hs, W.shape[0])
-        if self._mode != 0:
-            # padded modes: gradients on the padded tensor, folded back, then the elementwise MU kernel
-            neg, pos = self.reconstruction_gradient_H(V, W, H, s)
-            self.multiplicative_update(Hs, neg, pos, eps + (sparsity if sparsity > 0 else 0.))
+        lateral = inhibition > 0 or cross_inhibition > 0
+        if self._mode != 0 or lateral:
+            k = len(self.atom_shape)
+            ks = [np.ascontiguousarray(kk, dtype=np.float64) for kk in (inhibition_kernels or ())]
+            if lateral and len(ks) != k:
+                raise ValueError('one inhibition kernel per shift axis')
+            kp = [kk.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for kk in ks] + [None, None]
+            kl = [len(kk) for kk in ks] + [0, 0]
+            Rs = self._R_scratch[ls]
+            self._foreign_H()     # (what the cache holds about these samples is about to be stale)
+
+            def run_ex(Hc, ld):
+                with self._timed('update_H'):
+                    rc = self._lib.tnmf_hip_update_H_ex(
+                        self._ctx, ctypes.byref(self._geom(Hc.shape[0], W.shape[0], ld)), self._mode, _ptr(Vs), _ptr(W),
+                        _ptr(Hc), _ptr(Rs), float(eps), float(sparsity), float(inhibition), float(cross_inhibition),
+                        kp[0], kl[0], kp[1], kl[1], self._stream())
+                return rc, 'tnmf_hip_update_H_ex'
+
+            if self._mode != 0:
+                assert Hs.is_contiguous()
+                rc, where = run_ex(Hs, 0)
+                _lib.check(rc, where)
+            else:
+                self._call_H(Hs, True, run_ex)
+            self._foreign_H()
             return
         Rs = self._R_scratch[ls]
         self._validate_H_cache(Hs, W)

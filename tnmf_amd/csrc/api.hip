@@ -65,29 +65,34 @@ Scratch plan_scratch(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
     return s;
 }
 
-int ensure_scratch(tnmf_hip_ctx *ctx, size_t bytes) {
-    if (bytes <= ctx->ws_bytes) return TNMF_OK;
+int ensure_buffer(void **buf, size_t *have, size_t bytes, bool slack);
+
+int ensure_scratch(tnmf_hip_ctx *ctx, size_t bytes) { return ensure_buffer(&ctx->ws, &ctx->ws_bytes, bytes, true); }
+int ensure_hwork(tnmf_hip_ctx *ctx, size_t bytes) { return ensure_buffer(&ctx->hw, &ctx->hw_bytes, bytes, false); }
+
+int ensure_buffer(void **buf, size_t *have, size_t bytes, bool slack) {
+    if (bytes <= *have) return TNMF_OK;
     // the larger buffer is allocated BEFORE the current one is released, so a failure leaves the working one in place;
     // when both do not fit side by side the old order (release, then allocate) is tried once
-    const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    const size_t want = align_up(bytes + (slack ? bytes / 8 : 0), 1 << 20);
     void *bigger = nullptr;
     if (hipMalloc(&bigger, want) != hipSuccess) {
         (void)hipGetLastError();
         bigger = nullptr;
-        if (!ctx->ws) return TNMF_E_WORKSPACE;
+        if (!*buf) return TNMF_E_WORKSPACE;
     }
-    if (ctx->ws) {
+    if (*buf) {
         TNMF_HIP_TRY(hipDeviceSynchronize());
-        TNMF_HIP_TRY(hipFree(ctx->ws));
-        ctx->ws = nullptr;
-        ctx->ws_bytes = 0;
+        TNMF_HIP_TRY(hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
     }
     if (!bigger && hipMalloc(&bigger, want) != hipSuccess) {
         (void)hipGetLastError();
         return TNMF_E_WORKSPACE;
     }
-    ctx->ws = bigger;
-    ctx->ws_bytes = want;
+    *buf = bigger;
+    *have = want;
     return TNMF_OK;
 }
 
@@ -162,9 +167,13 @@ int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, co
     return generic_reconstruct(ctx, g, dtype, W, H, R, s);
 }
 
+// extra (fused only, may be NULL): a further term of the denominator, laid out like H (the lateral inhibition terms).
+// Kernel families without an epilogue for it answer TNMF_E_UNSUPPORTED / TNMF_E_STRIDE before touching anything; the
+// caller then takes the unfused gradient and launch_mu_update_extra.
 int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W, void *Hio,
-              void *neg, void *pos, bool fused, double reg, hipStream_t s) {
+              void *neg, void *pos, bool fused, double reg, hipStream_t s, const void *extra = nullptr) {
     if (g.N == 0) return TNMF_OK;
+    if (extra && (!fused || ctx->path == TNMF_PATH_FFT)) return TNMF_E_UNSUPPORTED;
     // (AUTO never takes the FFT family here, although it is the faster one for heavy atoms -- 46 vs 53 ms per iteration
     // at config 5's shard, C*Ay*Ax = 768: its float32 transform noise leaves 4e-4 of max|H| in the activations, and the
     // parity bar of the default path is 1e-5 on W AND H.  path = FFT is the opt-in.)
@@ -173,19 +182,20 @@ int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const v
     if (fused) fft_invalidate_H(ctx, g, dtype, Hio);   // the direct kernels are about to change H: its cached spectra are stale
     if (use_split(ctx, g, dtype)) {
         const int rc = split_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio,
-                                    (float *)neg, (float *)pos, fused, (float)reg, s);
+                                    (float *)neg, (float *)pos, fused, (float)reg, s, (const float *)extra);
         if (rc == TNMF_OK) ctx->last_path = "split";
         if (rc != TNMF_E_UNSUPPORTED) return rc;
     }
     if (fused && g.Hs != g.Hx) return TNMF_E_STRIDE;   // (nothing has been written yet)
     if (use_mfma(ctx, g, dtype, kCorrW)) {
+        if (extra) return TNMF_E_UNSUPPORTED;   // (the f32 MFMA kernel has no extra-term epilogue)
         ctx->last_path = "mfma";
         return mfma_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio, (float *)neg,
                            (float *)pos, fused, (float)reg, s);
     }
     if (ctx->path == TNMF_PATH_MFMA || ctx->path == TNMF_PATH_SPLIT) return TNMF_E_UNSUPPORTED;
     ctx->last_path = "generic";
-    return generic_corr_W(ctx, g, dtype, V, R, W, Hio, neg, pos, fused, reg, s);
+    return generic_corr_W(ctx, g, dtype, V, R, W, Hio, neg, pos, fused, reg, s, extra);
 }
 
 int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, const void *V, const void *R,
@@ -286,12 +296,13 @@ int tnmf_hip_ctx_create(int device_id, tnmf_hip_ctx **out) {
 int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx) {
     if (!ctx) return TNMF_OK;
     int rc = TNMF_OK;
-    if (ctx->ws || ctx->fft.ws || ctx->wimg) {
+    if (ctx->ws || ctx->fft.ws || ctx->wimg || ctx->hw) {
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
     }
     fft_release(ctx);
     split_release(ctx);
+    if (ctx->hw) (void)hipFree(ctx->hw);
     if (ctx->ws) {
         const hipError_t e = hipFree(ctx->ws);
         if (e != hipSuccess) rc = (int)e;
@@ -495,6 +506,78 @@ int tnmf_hip_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *
     double reg = eps;
     if (sparsity > 0) reg += sparsity;  // TransformInvariantNMF.py:227-230
     return do_corr_W(ctx, g, dtype, V, Rs, W, H_inout, nullptr, nullptr, true, reg, s);
+}
+
+int tnmf_hip_update_H_ex(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *V, const void *W,
+                         void *H_inout, void *R_scratch, double eps, double sparsity, double inhibition,
+                         double cross_inhibition, const double *kernel0, int len0, const double *kernel1, int len1,
+                         void *stream) {
+    ENTER(ctx, geom);
+    if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
+    if (g.N == 0) return TNMF_OK;
+    if (!V || !W || !H_inout) return TNMF_E_NULL;
+    const bool lateral = inhibition > 0 || cross_inhibition > 0;
+    if (lateral && (!kernel0 || (geom->ndim == 2 && !kernel1))) return TNMF_E_NULL;
+    if (inhibition < 0 || cross_inhibition < 0) return TNMF_E_GEOM;
+    double reg = eps;
+    if (sparsity > 0) reg += sparsity;  // TransformInvariantNMF.py:227-230
+    const size_t es = esize(dtype);
+    void *Rs = R_scratch;
+    if (!Rs) {
+        const Scratch sc = plan_scratch(ctx, g, dtype);
+        CHECK(ensure_scratch(ctx, sc.total));
+        Rs = ws_at(ctx, sc.r_off);
+    }
+    // the reference's kernels come one per shift axis (TransformInvariantNMF.py:163): 1-D problems have the x kernel only
+    const double one = 1.0;
+    const double *ky = geom->ndim == 2 ? kernel0 : &one, *kx = geom->ndim == 2 ? kernel1 : kernel0;
+    const int ly = geom->ndim == 2 ? len0 : 1, lx = geom->ndim == 2 ? len1 : len0;
+    const double xc = cross_inhibition > 0 && g.M > 1 ? cross_inhibition / (g.M - 1) : 0.0;   // (:266-268)
+
+    if (mode == TNMF_MODE_VALID) {
+        const size_t nE = align_up((size_t)g.N * g.M * g.Hy * g.Hs * es, 256);
+        const size_t nG = align_up((size_t)g.N * g.M * g.Hy * g.Hx * es, 256);
+        void *E = nullptr;
+        if (lateral) {
+            CHECK(ensure_hwork(ctx, nE));
+            E = ctx->hw;
+            CHECK(launch_inhibition(ctx, dtype, g.N, g.M, g.Hy, g.Hs, H_inout, E, ky, ly, kx, lx, inhibition, xc, s));
+        }
+        CHECK(do_reconstruct(ctx, g, dtype, W, H_inout, Rs, s));
+        int rc = do_corr_W(ctx, g, dtype, V, Rs, W, H_inout, nullptr, nullptr, true, reg, s, E);
+        if (!E || (rc != TNMF_E_UNSUPPORTED && rc != TNMF_E_STRIDE)) return rc;
+        // this kernel family has no epilogue for the extra term (nothing has been written): unfused gradient into the
+        // work arrays, then one update kernel
+        if (ctx->hw_bytes < nE + 2 * nG) {
+            // (growing the buffer would lose E: take the larger buffer first, then compute E again)
+            CHECK(ensure_hwork(ctx, nE + 2 * nG));
+            E = ctx->hw;
+            CHECK(launch_inhibition(ctx, dtype, g.N, g.M, g.Hy, g.Hs, H_inout, E, ky, ly, kx, lx, inhibition, xc, s));
+        }
+        char *neg = static_cast<char *>(ctx->hw) + nE, *pos = neg + nG;
+        CHECK(do_corr_W(ctx, g, dtype, V, Rs, W, nullptr, neg, pos, false, 0.0, s));
+        fft_invalidate_H(ctx, g, dtype, H_inout);
+        return launch_mu_update_extra(ctx, dtype, H_inout, neg, pos, E, (size_t)g.N * g.M * g.Hy, g.Hx, g.Hs, reg, s);
+    }
+
+    // reconstruction modes: a 'valid' half step on the padded activations, folded back (adjoint of the pad) inside the
+    // update kernel.  H is C-contiguous with the shift shape of the mode.
+    if (g.Hs != g.Hx) return TNMF_E_STRIDE;
+    const int Sy = geom->ndim == 1 ? 1 : (mode == TNMF_MODE_FULL ? g.Dy - g.Ay + 1 : g.Dy);
+    const int Sx = mode == TNMF_MODE_FULL ? g.Dx - g.Ax + 1 : g.Dx;
+    if (Sy < 1 || Sx < 1) return TNMF_E_GEOM;
+    const size_t nP = align_up((size_t)g.N * g.M * g.Hy * g.Hx * es, 256);
+    const size_t nE = lateral ? align_up((size_t)g.N * g.M * Sy * Sx * es, 256) : 0;
+    CHECK(ensure_hwork(ctx, 3 * nP + nE));
+    char *Hp = static_cast<char *>(ctx->hw), *negp = Hp + nP, *posp = negp + nP;
+    void *E = lateral ? posp + nP : nullptr;
+    fft_invalidate(ctx);   // the padded copy lives at the same address every call, with new contents
+    CHECK(launch_pad_fold(ctx, g, dtype, mode, false, H_inout, Hp, s));
+    CHECK(do_reconstruct(ctx, g, dtype, W, Hp, Rs, s));
+    CHECK(do_corr_W(ctx, g, dtype, V, Rs, W, nullptr, negp, posp, false, 0.0, s));
+    if (lateral) CHECK(launch_inhibition(ctx, dtype, g.N, g.M, Sy, Sx, H_inout, E, ky, ly, kx, lx, inhibition, xc, s));
+    fft_invalidate(ctx);
+    return launch_fold_update(ctx, g, dtype, mode, Sy, Sx, H_inout, negp, posp, E, reg, s);
 }
 
 int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,

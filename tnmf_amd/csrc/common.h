@@ -64,6 +64,8 @@ struct tnmf_hip_ctx {
     int split;              // 1: the H gradient may run on the bf16 matrix cores with 3 x bf16 operand splits (split.hip)
     void *wimg;             // pre-split register images of W for split.hip
     size_t wimg_bytes;
+    void *hw = nullptr;     // activation-sized work arrays of tnmf_hip_update_H_ex (lateral terms, padded H, its gradients)
+    size_t hw_bytes = 0;
     FftState fft;
 };
 

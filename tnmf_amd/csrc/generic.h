@@ -8,8 +8,10 @@ constexpr int kEnergyPartials = 2048;  // per-block partial sums of the energy r
 int generic_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R,
                         hipStream_t s);
 // fused == false: writes neg/pos.  fused == true: H = (H * neg) / (pos + reg) in place (neg/pos unused).
+// extra (fused only, may be NULL): a further term of the denominator, laid out like H
 int generic_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *W,
-                   void *H_inout, void *neg, void *pos, bool fused, double reg, hipStream_t s);
+                   void *H_inout, void *neg, void *pos, bool fused, double reg, hipStream_t s,
+                   const void *extra = nullptr);
 // split-K partial sums: doubles, [P][M*C][Ay*Ax][2] in unflipped shift order
 int generic_corr_H_chunks(const tnmf_hip_ctx *ctx, const Geo &g);
 int generic_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *H,
@@ -30,3 +32,15 @@ int launch_convolve_axis(const tnmf_hip_ctx *ctx, int dtype, const void *in, voi
 // reconstruction modes: pad activations (fold == false) / fold the gradient back (fold == true); mode = TNMF_MODE_*
 int launch_pad_fold(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, int mode, bool fold, const void *in, void *out,
                     hipStream_t s);
+
+// inhibit.hip: lateral terms of the H half step and the fold + update of the reconstruction modes
+// E[N][M][Hy][ld] = inh * (G - H) + xc * (sum over atoms of G - G), G = separable zero-padded convolution of H (same layout)
+int launch_inhibition(const tnmf_hip_ctx *ctx, int dtype, int N, int M, int Hy, int ld, const void *H, void *E,
+                      const double *ky_host, int ly, const double *kx_host, int lx, double inh, double xc,
+                      hipStream_t s);
+// H[rows][Hx] (row stride ld) = H * neg / (pos + E + reg); neg / pos C-contiguous, E laid out like H or NULL
+int launch_mu_update_extra(const tnmf_hip_ctx *ctx, int dtype, void *H, const void *neg, const void *pos, const void *E,
+                           size_t rows, int Hx, int ld, double reg, hipStream_t s);
+// modes: H[N][M][Sy][Sx] = H * fold(negp) / (fold(posp) + E + reg), negp / posp on the padded shape (g.Hy, g.Hx)
+int launch_fold_update(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, int mode, int Sy, int Sx, void *H,
+                       const void *negp, const void *posp, const void *E, double reg, hipStream_t s);

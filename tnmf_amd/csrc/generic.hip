@@ -86,7 +86,8 @@ __global__ __launch_bounds__(kBlock) void k_reconstruct(Geo g, Tile t, const T *
 template <typename T, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_corr_W(Geo g, Tile t, const T *__restrict__ V, const T *__restrict__ Rr,
                                                    const T *__restrict__ W, T *__restrict__ Hio,
-                                                   T *__restrict__ neg, T *__restrict__ pos, T reg) {
+                                                   T *__restrict__ neg, T *__restrict__ pos, T reg,
+                                                   const T *__restrict__ extra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int SH = t.TY + g.Ay - 1, SW = t.TX + g.Ax - 1;
     const int nA = g.Ay * g.Ax;
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(kBlock) void k_corr_W(Geo g, Tile t, const T *__res
         const size_t o = (((size_t)n * g.M + m) * g.Hy + u) * g.Hx + vv;
         if (FUSED) {
             const T h = Hio[o];
+            if (extra) ap += extra[o];   // lateral inhibition terms (TransformInvariantNMF.py:253-269)
             Hio[o] = (h * an) / (ap + reg);
         } else {
             neg[o] = an;
@@ -418,7 +420,7 @@ int launch_reconstruct(const Geo &g, const void *W, const void *H, void *R, hipS
 
 template <typename T>
 int launch_corr_W(const Geo &g, const void *V, const void *R, const void *W, void *Hio, void *neg, void *pos,
-                  bool fused, double reg, hipStream_t s) {
+                  bool fused, double reg, hipStream_t s, const void *extra) {
     const Tile t = make_tile(g.Hy, g.Hx);
     const size_t lds = (2 * (size_t)(t.TY + g.Ay - 1) * (t.TX + g.Ax - 1) + (size_t)g.Ay * g.Ax) * sizeof(T);
     if (lds > 64 * 1024) return TNMF_E_UNSUPPORTED;
@@ -426,10 +428,10 @@ int launch_corr_W(const Geo &g, const void *V, const void *R, const void *W, voi
     if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
     if (fused)
         hipLaunchKernelGGL((k_corr_W<T, true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, g, t, (const T *)V,
-                           (const T *)R, (const T *)W, (T *)Hio, (T *)nullptr, (T *)nullptr, (T)reg);
+                           (const T *)R, (const T *)W, (T *)Hio, (T *)nullptr, (T *)nullptr, (T)reg, (const T *)extra);
     else
         hipLaunchKernelGGL((k_corr_W<T, false>), dim3((unsigned)blocks), dim3(kBlock), lds, s, g, t, (const T *)V,
-                           (const T *)R, (const T *)W, (T *)nullptr, (T *)neg, (T *)pos, (T)0);
+                           (const T *)R, (const T *)W, (T *)nullptr, (T *)neg, (T *)pos, (T)0, (const T *)nullptr);
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
 }
@@ -463,9 +465,9 @@ int generic_reconstruct(tnmf_hip_ctx *, const Geo &g, int dtype, const void *W, 
 }
 
 int generic_corr_W(tnmf_hip_ctx *, const Geo &g, int dtype, const void *V, const void *R, const void *W,
-                   void *H_inout, void *neg, void *pos, bool fused, double reg, hipStream_t s) {
-    return dtype == 0 ? launch_corr_W<float>(g, V, R, W, H_inout, neg, pos, fused, reg, s)
-                      : launch_corr_W<double>(g, V, R, W, H_inout, neg, pos, fused, reg, s);
+                   void *H_inout, void *neg, void *pos, bool fused, double reg, hipStream_t s, const void *extra) {
+    return dtype == 0 ? launch_corr_W<float>(g, V, R, W, H_inout, neg, pos, fused, reg, s, extra)
+                      : launch_corr_W<double>(g, V, R, W, H_inout, neg, pos, fused, reg, s, extra);
 }
 
 int generic_corr_H_chunks(const tnmf_hip_ctx *ctx, const Geo &g) {

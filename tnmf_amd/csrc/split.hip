@@ -7,7 +7,8 @@
 
 #define DECL(AY_, NR4_)                                                                                              \
     int split_launch_##AY_##_##NR4_(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *W, \
-                                    float *H_inout, float *neg, float *pos, bool fused, float reg, hipStream_t s);   \
+                                    float *H_inout, float *neg, float *pos, bool fused, float reg, hipStream_t s,    \
+                                    const float *extra);                                                             \
     int split_prepare_##AY_##_##NR4_();
 TNMF_SPLIT_SHAPES(DECL)
 #undef DECL
@@ -37,10 +38,10 @@ int split_prepare_device() {
 }
 
 int split_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *W, float *H_inout,
-                 float *neg, float *pos, bool fused, float reg, hipStream_t s) {
+                 float *neg, float *pos, bool fused, float reg, hipStream_t s, const float *extra) {
     const int nr4 = (g.Ax + 3) / 4;
 #define DISPATCH(AY_, NR4_) \
-    if (g.Ay == AY_ && nr4 == NR4_) return split_launch_##AY_##_##NR4_(ctx, g, V, R, W, H_inout, neg, pos, fused, reg, s);
+    if (g.Ay == AY_ && nr4 == NR4_) return split_launch_##AY_##_##NR4_(ctx, g, V, R, W, H_inout, neg, pos, fused, reg, s, extra);
     TNMF_SPLIT_SHAPES(DISPATCH)
 #undef DISPATCH
     return TNMF_E_UNSUPPORTED;

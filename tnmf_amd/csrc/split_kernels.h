@@ -167,13 +167,17 @@ __global__ void k_split_prep_W(Geo g, int NP, int NSLOT, int KB, const float *__
     }
 }
 
-template <bool FUSED, bool MULTI, int AY, int NR4>
+// EXTRA (fused updates on row-padded activations only): a further term of the denominator, laid out like H -- the lateral
+// inhibition terms of TransformInvariantNMF.py:253-269 (inhibit.hip computes them) -- is loaded behind the MFMA loop,
+// into the registers the operand buffers have just left, and added to pos in the epilogue.
+template <bool FUSED, bool MULTI, int AY, int NR4, bool EXTRA = false>
 __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(Geo g, int tiles_y, int tiles_x, int ablate,
                                                             unsigned long long *dbg,
                                                             const float *__restrict__ V, const float *__restrict__ Rr,
                                                             const u32x4 *__restrict__ Wimg, float *__restrict__ Hio,
                                                             float *__restrict__ neg, float *__restrict__ pos,
-                                                            float reg) {
+                                                            float reg, const float *__restrict__ Ex) {
+    static_assert(!EXTRA || FUSED, "the extra denominator term belongs to the fused update");
     using Cfg = SplitCfg<AY, NR4>;
     constexpr int WSTR = Cfg::WSTR, Q = Cfg::Q, planeB = Cfg::planeB, KB = Cfg::KB, NSLOT = Cfg::NSLOT, NP = Cfg::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -503,6 +507,22 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
         }
 
         SP_STAMP(4);     // MFMA loop
+        float ev[SP_RB][16];
+        if constexpr (EXTRA && LAST) {
+            const __amdgpu_buffer_rsrc_t ersrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(Ex + (size_t)n * g.M * g.Hy * hs), 0, (int)(g.M * plane4), 0x00020000);
+#pragma unroll
+            for (int rb = 0; rb < SP_RB; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(ersrc, (int)(hoff[rb] + 8u * q * plane4), 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned w = t4[e];
+                        ev[rb][4 * q + e] = __builtin_bit_cast(float, w);
+                    }
+                }
+        }
         if (more) convert(st + 1);   // before the stores below (see convert)
         SP_STAMP(5);     // convert (the prefetched window has landed under the loop)
 
@@ -577,7 +597,9 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
                         // H * neg / (pos + reg) with the hardware reciprocal (v_rcp_f32, 1 ulp; pos + reg > 0): ~2 ulp, inside
                         // the f32 parity budget.  (__fdividef compiles to the full IEEE division sequence here: ten
                         // instructions per element.)
-                        const float ov = FUSED ? hv[rb][4 * q + e] * nv * __builtin_amdgcn_rcpf(pv_ + reg) : 0.f;
+                        float den = pv_ + reg;
+                        if constexpr (EXTRA) den = (pv_ + ev[rb][4 * q + e]) + reg;
+                        const float ov = FUSED ? hv[rb][4 * q + e] * nv * __builtin_amdgcn_rcpf(den) : 0.f;
                         o4[e] = __builtin_bit_cast(unsigned, ov);
                         n4[e] = __builtin_bit_cast(unsigned, nv);
                         q4[e] = __builtin_bit_cast(unsigned, pv_);
@@ -627,8 +649,10 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
 
 template <int AY, int NR4>
 int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *W, float *H_inout,
-           float *neg, float *pos, bool fused, float reg, hipStream_t s) {
+           float *neg, float *pos, bool fused, float reg, hipStream_t s, const float *extra) {
     using Cfg = SplitCfg<AY, NR4>;
+    // the extra-term epilogue loads whole 16-byte groups at H's own offsets: row-padded activations only
+    if (extra && (!fused || g.Hs % SP_TX != 0)) return TNMF_E_UNSUPPORTED;
     const int MT = cdiv(g.M, 32);
     const size_t wbytes = (size_t)MT * g.C * Cfg::wimg;
     if (wbytes > ctx->wimg_bytes) {
@@ -658,19 +682,24 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
     const size_t nw = (size_t)P * MT * 4;
     static const bool want_stamps = tnmf_diag_env("TNMF_HIP_STAMPS") != nullptr;   // -DTNMF_DIAG builds only
     if (want_stamps) TNMF_HIP_TRY(hipMalloc(&dbg, nw * 8 * sizeof(unsigned long long)));
-#define SPLIT_LAUNCH(FUSED_, MULTI_, H_, NEG_, POS_, REG_)                                                          \
-    hipLaunchKernelGGL((k_split_corr_W<FUSED_, MULTI_, AY, NR4>), grid, dim3(kBlock), Cfg::lds, s, g, tiles_y, tiles_x, \
-                       ctx->ablate, dbg, V, R, (const u32x4 *)ctx->wimg, H_, NEG_, POS_, REG_)
-    if (fused) {
+#define SPLIT_LAUNCH(FUSED_, MULTI_, EXTRA_, H_, NEG_, POS_, REG_)                                                   \
+    hipLaunchKernelGGL((k_split_corr_W<FUSED_, MULTI_, AY, NR4, EXTRA_>), grid, dim3(kBlock), Cfg::lds, s, g, tiles_y,   \
+                       tiles_x, ctx->ablate, dbg, V, R, (const u32x4 *)ctx->wimg, H_, NEG_, POS_, REG_, extra)
+    if (fused && extra) {
         if (g.C > 1)
-            SPLIT_LAUNCH(true, true, H_inout, (float *)nullptr, (float *)nullptr, reg);
+            SPLIT_LAUNCH(true, true, true, H_inout, (float *)nullptr, (float *)nullptr, reg);
         else
-            SPLIT_LAUNCH(true, false, H_inout, (float *)nullptr, (float *)nullptr, reg);
+            SPLIT_LAUNCH(true, false, true, H_inout, (float *)nullptr, (float *)nullptr, reg);
+    } else if (fused) {
+        if (g.C > 1)
+            SPLIT_LAUNCH(true, true, false, H_inout, (float *)nullptr, (float *)nullptr, reg);
+        else
+            SPLIT_LAUNCH(true, false, false, H_inout, (float *)nullptr, (float *)nullptr, reg);
     } else {
         if (g.C > 1)
-            SPLIT_LAUNCH(false, true, (float *)nullptr, neg, pos, 0.f);
+            SPLIT_LAUNCH(false, true, false, (float *)nullptr, neg, pos, 0.f);
         else
-            SPLIT_LAUNCH(false, false, (float *)nullptr, neg, pos, 0.f);
+            SPLIT_LAUNCH(false, false, false, (float *)nullptr, neg, pos, 0.f);
     }
 #undef SPLIT_LAUNCH
     TNMF_LAUNCH_CHECK();
@@ -696,13 +725,15 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
 
 template <int AY, int NR4>
 int prepare_one() {
-#define SPLIT_ATTR(FUSED_, MULTI_)                                                              \
-    TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_split_corr_W<FUSED_, MULTI_, AY, NR4>,     \
+#define SPLIT_ATTR(FUSED_, MULTI_, EXTRA_)                                                          \
+    TNMF_HIP_TRY(hipFuncSetAttribute((const void *)k_split_corr_W<FUSED_, MULTI_, AY, NR4, EXTRA_>, \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-    SPLIT_ATTR(true, true);
-    SPLIT_ATTR(true, false);
-    SPLIT_ATTR(false, true);
-    SPLIT_ATTR(false, false);
+    SPLIT_ATTR(true, true, false);
+    SPLIT_ATTR(true, false, false);
+    SPLIT_ATTR(false, true, false);
+    SPLIT_ATTR(false, false, false);
+    SPLIT_ATTR(true, true, true);
+    SPLIT_ATTR(true, false, true);
 #undef SPLIT_ATTR
     return TNMF_OK;
 }

@@ -9,8 +9,8 @@
 int TNMF_SPLIT_CAT(split_launch_, TNMF_SPLIT_AY, TNMF_SPLIT_NR4)(tnmf_hip_ctx *ctx, const Geo &g, const float *V,
                                                                  const float *R, const float *W, float *H_inout,
                                                                  float *neg, float *pos, bool fused, float reg,
-                                                                 hipStream_t s) {
-    return launch<TNMF_SPLIT_AY, TNMF_SPLIT_NR4>(ctx, g, V, R, W, H_inout, neg, pos, fused, reg, s);
+                                                                 hipStream_t s, const float *extra) {
+    return launch<TNMF_SPLIT_AY, TNMF_SPLIT_NR4>(ctx, g, V, R, W, H_inout, neg, pos, fused, reg, s, extra);
 }
 
 int TNMF_SPLIT_CAT(split_prepare_, TNMF_SPLIT_AY, TNMF_SPLIT_NR4)() {
