@@ -240,6 +240,9 @@ def main():
                     help='full: full-batch MU iterations; cyclic: Cyclic-MU epochs over mini-batches (configs 4, 5)')
     ap.add_argument('--batch-size', type=int, default=None, help='global mini-batch size of --algorithm cyclic '
                     '(default: a quarter of the global sample count)')
+    ap.add_argument('--inhibition', type=float, default=0., help='lateral inhibition strength of the H half step '
+                    '(reference inhibition_strength; default range = atom size - 1)')
+    ap.add_argument('--cross-inhibition', type=float, default=0., help='cross-atom inhibition strength')
     ap.add_argument('--reduce', default='all_reduce', choices=['all_reduce', 'ordered'],
                     help="cross-rank sum of the W gradient: one RCCL all-reduce, or all-gather + fixed rank-order sum")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -375,13 +378,13 @@ def main():
         b = model._backend
         if args.algorithm == 'cyclic':
             batches = b.minibatch_slices(batch_size)
-            h_args = dict(sparsity=0., inhibition=0., cross_inhibition=0.)
+            h_args = dict(sparsity=0., inhibition=args.inhibition, cross_inhibition=args.cross_inhibition)
 
             def step():
                 model._epoch_cyclic(None, batches, h_args, 1.)
         else:
             def step():
-                model._update_H()
+                model._update_H(inhibition=args.inhibition, cross_inhibition=args.cross_inhibition)
                 model._update_W()
 
         def fence():
@@ -509,7 +512,8 @@ def main():
                             f'{"x".join(map(str, cfg["D"]))} per GPU, {cfg["M"]} atoms '
                             f'{"x".join(map(str, cfg["A"]))} (BASELINE.json configs[{args.config - 1}])',
                 'samples_per_gpu': n_local, 'global_samples': n_global, 'path': args.path, 'kernel_path': main_family,
-                'kernel_families': paths, 'algorithm': args.algorithm,
+                'kernel_families': paths, 'algorithm': args.algorithm, 'inhibition': args.inhibition,
+                'cross_inhibition': args.cross_inhibition,
                 'batch_size': batch_size if args.algorithm == 'cyclic' else None,
                 'h_update_arithmetic': ('3 x bf16 operand splits on the bf16 matrix cores (float32-grade; parity '
                                         'object and exact_f32_variant beside it)' if 'split' in fams else
