@@ -69,6 +69,9 @@ CONFIGS = {
     6: dict(N=256, C=1, D=(245, 245), M=32, A=(12, 12)),
     # not a BASELINE config: long 1-D signals (config 1's kind of data at a size that is not launch-bound)
     7: dict(N=2048, C=3, D=(500,), M=32, A=(64,)),
+    # not a BASELINE config: the geometry of the reference's mini-batch tests (tnmf/tests/test_minibatch.py:35-73: 768
+    # patches 1 x 32 x 32, 10 atoms 7 x 7, batch_size 3) -- small-batch stochastic schedules are launch-latency bound
+    8: dict(N=768, C=1, D=(32, 32), M=10, A=(7, 7)),
 }
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector = f32 MFMA
 PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
@@ -236,8 +239,12 @@ def main():
     ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument('--samples', type=int, default=None, help='override samples per GPU (debug)')
     ap.add_argument('--path', default='auto', choices=['auto', 'generic', 'mfma', 'split', 'fft', 'hybrid'])
-    ap.add_argument('--algorithm', default='full', choices=['full', 'cyclic'],
-                    help='full: full-batch MU iterations; cyclic: Cyclic-MU epochs over mini-batches (configs 4, 5)')
+    ap.add_argument('--algorithm', default='full', choices=['full', 'cyclic', 'asg', 'gsg', 'asag', 'gsag'],
+                    help='full: full-batch MU iterations; cyclic: Cyclic-MU epochs over mini-batches (configs 4, 5); '
+                         'asg / gsg / asag / gsag: one epoch of the stochastic schedules (reference '
+                         'TransformInvariantNMF.py:467-504) per step')
+    ap.add_argument('--eager', action='store_true', help='stochastic schedules: drive every batch from Python '
+                    '(one C-ABI call per half step) instead of one tnmf_hip_run_schedule call per epoch')
     ap.add_argument('--batch-size', type=int, default=None, help='global mini-batch size of --algorithm cyclic '
                     '(default: a quarter of the global sample count)')
     ap.add_argument('--inhibition', type=float, default=0., help='lateral inhibition strength of the H half step '
@@ -376,16 +383,23 @@ def main():
                                       path=path, init='device', process_group=pg, split=split, reduce=args.reduce)
         model._initialize_matrices(V, keep_W=False)
         b = model._backend
-        if args.algorithm == 'cyclic':
+        if args.algorithm != 'full':
             batches = b.minibatch_slices(batch_size)
             h_args = dict(sparsity=0., inhibition=args.inhibition, cross_inhibition=args.cross_inhibition)
+            epoch_fn = getattr(model, '_epoch_' + args.algorithm)
+            if args.eager:
+                model._use_schedules = False
+            state = [None]
 
             def step():
-                model._epoch_cyclic(None, batches, h_args, 1.)
+                state[0] = epoch_fn(state[0], batches, h_args, 0.8 if args.algorithm in ('asag', 'gsag') else 1.)
         else:
+            it_args = dict(sparsity=0., inhibition=args.inhibition, cross_inhibition=args.cross_inhibition)
+            if args.eager:
+                model._use_schedules = False
+
             def step():
-                model._update_H(inhibition=args.inhibition, cross_inhibition=args.cross_inhibition)
-                model._update_W()
+                model._iteration(it_args)
 
         def fence():
             if pg is not None:
@@ -492,29 +506,38 @@ def main():
         # FFT-family groups are several kernels each, none of them longer.  Under --path fft the H update is a group
         # too: the group with the largest total time is reported then.
         single = [n for n in rl if paths.get(n) in ('split', 'mfma', 'generic') and n == 'update_H']
-        dom = single[0] if single else max(rl, key=lambda n: kernels[n]['total_ms'])
         ms_per_step = elapsed / args.steps * 1e3
-        roof = dict(rl[dom])
-        roof['dominance'] = ('longest single kernel of the step' if single else
-                             'kernel group with the largest total time (every group is several kernels on this path)')
-        main_kernel = GROUP_KERNELS.get(dom, {}).get(paths.get(dom), (dom, ()))[0]
-        prof_ms, prof_file = rocprof_average_ms(args.config, main_kernel) if args.algorithm == 'full' and not args.samples else (None, None)
-        roof['rocprof_avg_launch_ms'] = prof_ms
-        roof['rocprof_file'] = prof_file
+        if rl:
+            dom = single[0] if single else max(rl, key=lambda n: kernels[n]['total_ms'])
+            roof = dict(rl[dom])
+            roof['dominance'] = ('longest single kernel of the step' if single else
+                                 'kernel group with the largest total time (every group is several kernels on this path)')
+            main_kernel = GROUP_KERNELS.get(dom, {}).get(paths.get(dom), (dom, ()))[0]
+            prof_ms, prof_file = (rocprof_average_ms(args.config, main_kernel)
+                                  if args.algorithm == 'full' and not args.samples else (None, None))
+            roof['rocprof_avg_launch_ms'] = prof_ms
+            roof['rocprof_file'] = prof_file
+        else:
+            # a whole epoch issued by one library call (tnmf_hip_run_schedule): no per-kernel events; the step is a chain
+            # of tiny dependent launches, bound by launch latency, not by a roofline
+            roof = {'kernel': 'tnmf_hip_run_schedule (whole epoch)', 'bound': 'latency', 'achieved': None, 'peak': None,
+                    'unit': None, 'frac': None, 'traffic': None,
+                    'alg_tflops': 6 * F / (ms_per_step * 1e-3) / 1e12}
         line = {
             'metric': 'MU-iterations/sec', 'value': world * args.steps / elapsed, 'unit': 'MU-iterations/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
                 'workload': (f'{k}-D shift-invariant MU, full batch: ' if args.algorithm == 'full' else
-                             f'{k}-D shift-invariant MU, Cyclic-MU epochs (global batch {batch_size}): ') +
+                             f'{k}-D shift-invariant MU, {args.algorithm.upper()}-MU epochs (global batch {batch_size}'
+                             f'{", driven batch by batch from Python" if args.eager else ""}): ') +
                             f'{n_local} samples x {cfg["C"]} ch x '
                             f'{"x".join(map(str, cfg["D"]))} per GPU, {cfg["M"]} atoms '
                             f'{"x".join(map(str, cfg["A"]))} (BASELINE.json configs[{args.config - 1}])',
                 'samples_per_gpu': n_local, 'global_samples': n_global, 'path': args.path, 'kernel_path': main_family,
                 'kernel_families': paths, 'algorithm': args.algorithm, 'inhibition': args.inhibition,
                 'cross_inhibition': args.cross_inhibition,
-                'batch_size': batch_size if args.algorithm == 'cyclic' else None,
+                'batch_size': batch_size if args.algorithm != 'full' else None,
                 'h_update_arithmetic': ('3 x bf16 operand splits on the bf16 matrix cores (float32-grade; parity '
                                         'object and exact_f32_variant beside it)' if 'split' in fams else
                                         'exact f32' if paths.get('update_H') in ('mfma', 'generic') else 'fft'),

@@ -38,7 +38,7 @@ enum {
     TNMF_E_DTYPE = -3,     /* dtype not 0/1 */
     TNMF_E_WORKSPACE = -4, /* workspace allocation failed */
     TNMF_E_UNSUPPORTED = -5,
-    TNMF_E_STRIDE = -6     /* h_row_stride > shift width, and the kernel family this call dispatches to wants C-contiguous H */
+    TNMF_E_STRIDE = -6     /* h_row_stride > shift width, and the kernel family forced for this call wants C-contiguous H */
 };
 
 typedef struct tnmf_hip_ctx tnmf_hip_ctx;
@@ -54,8 +54,9 @@ typedef struct {
     /* Row stride of H in elements; 0 (or the shift width D[last] + A[last] - 1) = C-contiguous, as the reference's arrays
      * are.  A larger value describes activations whose rows are padded to whole cache lines: H[n,m,y,x] at
      * ((n*M + m)*Hy + y)*h_row_stride + x, the plane and sample strides following from it.  Supported where H is
-     * streamed by the FFT family and the split kernel (the default dispatch of float32 problems the hybrid covers);
-     * every other kernel family answers TNMF_E_STRIDE and touches nothing -- the caller then passes a contiguous copy.
+     * streamed by the FFT family, the split kernel and the generic kernels -- everything TNMF_PATH_AUTO dispatches to for
+     * such activations; only the f32 MFMA kernels want C-contiguous rows (AUTO skips them for padded ones; with
+     * TNMF_PATH_MFMA forced the call answers TNMF_E_STRIDE and touches nothing -- the caller then passes a contiguous copy).
      * Outputs shaped like H (neg / pos of tnmf_hip_grad_H) are always C-contiguous. */
     int h_row_stride;
 } tnmf_hip_geom;
@@ -112,8 +113,8 @@ int tnmf_hip_ctx_invalidate(tnmf_hip_ctx *ctx);
  * mini-batch slice, the way the reference's backends receive `H[s]` (tnmf/backends/NumPy.py:77-80,101) -- works on the
  * matching sample range of ONE cache with per-sample validity: a Cyclic-MU epoch transforms every batch once, like a
  * full-batch iteration (the reference's counterpart: per-slice caches, tnmf/backends/NumPy_CachingFFT.py:143-158).
- * Such slices also follow the kernel-family choice of the resident problem (TNMF_PATH_AUTO decides by its size, not
- * the slice's), so row-padded activations never meet a family that wants them C-contiguous.  Without a binding the cache
+ * (TNMF_PATH_AUTO still picks the kernel family by the size of the slice itself: small batches take the direct kernels,
+ * which read row-padded activations through the row stride.)  Without a binding the cache
  * follows the operands of the last call.  H == NULL or geom == NULL drops the binding.  The binding holds no reference:
  * the caller re-binds (or invalidates) when the buffers are replaced. */
 int tnmf_hip_ctx_bind(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *H, const void *V);
@@ -199,6 +200,29 @@ int tnmf_hip_update_H_ex(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode,
  *   R_scratch / r_is_valid as for tnmf_hip_update_H. */
 int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,
                           void *R_scratch, int r_is_valid, void *negpos, void *stream);
+
+/* ---- mini-batch schedules in one call ---------------------------------------------------------------------------------
+ * The stochastic schedules of the reference (ASG / GSG / ASAG / GSAG, TransformInvariantNMF.py:467-504, and Cyclic-MU,
+ * :457-465) are chains of small dependent steps -- with batch_size 3, an H half step on 3 samples, a W gradient on the
+ * same 3, a W update, 256 times per epoch -- whose cost driven batch by batch from the host is launch latency and
+ * interpreter time.  tnmf_hip_run_schedule takes a whole epoch as a list of operations on sample ranges of the resident
+ * problem and issues every kernel from one host call:
+ *   TNMF_OP_UPDATE_H  H[n0:n1] *= corr(W, V) / (corr(W, R) + eps + sparsity)            (= tnmf_hip_update_H on the slice)
+ *   TNMF_OP_GRAD_W    acc = a * acc + b * [neg | pos](V, H)[n0:n1]    (a == 0: acc = b * g; _accumulate_gradient_W,
+ *                     :444-455, with (a, b) = (1, 1), (1 - lambda, lambda) or, from the integer start (0, 0), (0, lambda))
+ *   TNMF_OP_APPLY_W   W = W * acc_neg / (acc_pos + eps), normalised; acc_pos is left incremented by eps (:232)
+ * geom->N = samples of the resident problem (V, H_inout point at sample 0); acc: device buffer [2,M,C,*A] that persists
+ * between calls where the schedule says so (ASAG / GSAG).  Single device: with several ranks the gradient must be summed
+ * across them between GRAD_W and APPLY_W, which is the caller's collective. */
+enum { TNMF_OP_UPDATE_H = 0, TNMF_OP_GRAD_W = 1, TNMF_OP_APPLY_W = 2 };
+typedef struct {
+    int kind;    /* TNMF_OP_* */
+    int n0, n1;  /* sample range [n0, n1) of the resident problem (may be empty) */
+    double a, b; /* TNMF_OP_GRAD_W */
+} tnmf_hip_op;
+int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, void *W_inout, void *H_inout,
+                          void *R_scratch, void *acc, const tnmf_hip_op *ops, int n_ops, double eps, double sparsity,
+                          void *stream);
 
 /* Deterministic cross-rank reduction of the [neg | pos] buffer ("all-gather ... then sum in rank order"):
  *   out[i] = ((parts[0][i] + parts[1][i]) + parts[2][i]) + ...   for the n_parts buffers of n_elems elements that the

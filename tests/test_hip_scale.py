@@ -604,3 +604,34 @@ def test_lateral_terms_and_modes_run_inside_the_library(path, mode, lateral):
     assert dW < 1e-5 and gap < 1e-5, (dW, dH, gap)
     if path != 'fft':        # (path='fft' makes no parity claim on H in float32)
         assert dH < 1e-5, dH
+
+
+@pytest.mark.parametrize('algorithm', ['Cyclic_MU', 'ASG_MU', 'GSG_MU', 'ASAG_MU', 'GSAG_MU'])
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-11), (np.float32, 1e-5)], ids=['f64', 'f32'])
+def test_schedules_in_one_call_match_the_batch_by_batch_path(algorithm, dtype, tol):
+    """tnmf_hip_run_schedule (one library call per epoch) against the same schedule driven batch by batch from Python and
+    against the oracle's front end (reference TransformInvariantNMF.py:444-504): small batches (2 of 7 samples, a ragged
+    last batch), 3 epochs, sag_lambda 0.8 -- the accumulator of ASAG / GSAG persists across the calls."""
+    N, C, D, M, A = 7, 2, (20, 24), 5, (4, 5)
+    V = planted_V(N, C, D, M, A, seed=21, dtype=dtype, density=0.05)
+    kw = dict(batch_size=2, n_epochs=3, sag_lambda=0.8, sparsity_H=0.05)
+    got = {}
+    for flavour in ('one_call', 'batch_by_batch'):
+        np.random.seed(42)
+        nmf = TransformInvariantNMF(n_atoms=M, atom_shape=A, backend='hip')
+        nmf._use_schedules = flavour == 'one_call'
+        calls = []
+        if flavour == 'one_call':
+            inner = nmf._backend.run_schedule
+            nmf._backend.run_schedule = lambda *a, **k: (calls.append(len(a[3])), inner(*a, **k))[1]
+        nmf.fit(V, algorithm=getattr(MiniBatchAlgorithm, algorithm), progress_callback=lambda *_: True, **kw)
+        if flavour == 'one_call':
+            assert len(calls) == 3 and min(calls) >= 4, calls          # one call per epoch, a whole epoch of operations
+        got[flavour] = (nmf.W, nmf.H, nmf._energy_function())
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c')
+    ref.fit(V.astype(np.float64), algorithm=getattr(orc.MiniBatchAlgorithm, algorithm), **kw)
+    for name, (W, H, E) in got.items():
+        dW, dH, gap = relmax(W, ref.W), relmax(H, ref.H), abs(E - ref.energy()) / ref.energy()
+        assert dW < tol and dH < tol and gap < tol, (name, dW, dH, gap)
+    assert relmax(got['one_call'][0], got['batch_by_batch'][0]) < (1e-13 if dtype == np.float64 else 1e-6)

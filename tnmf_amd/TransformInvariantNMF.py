@@ -97,6 +97,8 @@ class TransformInvariantNMF:
         self._logger = logger if logger is not None else logging.getLogger(self.__class__.__name__)
         self._logger.setLevel([logging.ERROR, logging.WARNING, logging.INFO, logging.DEBUG][verbose])
         self._use_fused = bool(use_fused_updates)
+        self._use_schedules = bool(use_fused_updates)   # mini-batch epochs as one backend call where the backend can
+        self._iteration_acc = None
 
         self._W = None
         self._H = None
@@ -180,6 +182,21 @@ class TransformInvariantNMF:
                 pos += term
         self._multiplicative_update(Hs, neg, pos, sparsity=sparsity)
 
+    def _iteration(self, h_args, update_H: bool = True, update_W: bool = True):
+        """One full-batch MU iteration (reference :334-340).  A problem small enough to be launch-latency bound goes to the
+        backend as one operation list (one persistent kernel launch per iteration, HIP_Backend.run_schedule)."""
+        run = self._scheduler(h_args)
+        if run is not None and getattr(self._backend, 'prefers_schedule', lambda *_: False)(self._H):
+            ops = ([('H', sliceNone)] if update_H else []) + ([('G', sliceNone, 0., 1.), ('W',)] if update_W else [])
+            if self._iteration_acc is None or self._iteration_acc.shape[1:] != self._W.shape:
+                self._iteration_acc = self._backend.new_gradient_accumulator(self._W)
+            run(self._V, self._W, self._H, ops, self._iteration_acc, sparsity=h_args['sparsity'], eps=self.eps)
+            return
+        if update_H:
+            self._update_H(**h_args)
+        if update_W:
+            self._update_W()
+
     def _initialize_matrices(self, V: np.ndarray, keep_W: bool):
         self._V = V
         self._W, self._H = self._backend.initialize(self._V, self.atom_shape, self.n_atoms,
@@ -201,12 +218,10 @@ class TransformInvariantNMF:
         assert update_H or update_W
         assert sparsity_H >= 0 and inhibition_strength >= 0 and cross_atom_inhibition_strength >= 0
         self._initialize_matrices(V, keep_W)
+        h_args = dict(sparsity=sparsity_H, inhibition=inhibition_strength,
+                      cross_inhibition=cross_atom_inhibition_strength)
         for iteration in range(n_iterations):
-            if update_H:
-                self._update_H(sparsity=sparsity_H, inhibition=inhibition_strength,
-                               cross_inhibition=cross_atom_inhibition_strength)
-            if update_W:
-                self._update_W()
+            self._iteration(h_args, update_H, update_W)
             if not self._report('Iteration', iteration, progress_callback):
                 break
         self._logger.info('TNMF finished.')
@@ -262,8 +277,35 @@ class TransformInvariantNMF:
         # NB: like the reference (:232), the update adds eps to the `pos` accumulator in place
         self._multiplicative_update(self._W, acc[0], acc[1], normalization_axes=self._axes_W_normalization)
 
+    # One epoch of a mini-batch schedule as ONE call of the backend (HIP_Backend.run_schedule -> tnmf_hip_run_schedule):
+    # the epoch functions below describe the epoch as a list of operations -- ('H', batch), ('G', batch, a, b) for
+    # acc = a * acc + b * gradient_W(batch), ('W',) for the W update from acc -- where the backend offers that and no
+    # lateral term is on (those go through tnmf_hip_update_H_ex batch by batch).
+    def _scheduler(self, h_args):
+        run = self._fused('run_schedule') if self._use_schedules else None
+        if run is None or not getattr(self._backend, 'supports_schedules', False):
+            return None
+        if h_args['inhibition'] > 0 or h_args['cross_inhibition'] > 0:
+            return None
+        return run
+
+    @staticmethod
+    def _blend_coefficients(first: bool, lam: float):
+        """(a, b) of acc = a * acc + b * g for reference :444-455; `first`: acc is still the integer 0 of :482/:495."""
+        if first:
+            return 0., (1. if lam == 1 else lam)
+        return (1., 1.) if lam == 1 else (1. - lam, lam)
+
     def _epoch_cyclic(self, _state, batches, h_args, _lam):
         """Algorithm 4: H per batch, W once per epoch from the summed gradient (reference :457-465)."""
+        run = self._scheduler(h_args)
+        if run is not None and len(batches):
+            ops = []
+            for i, batch in enumerate(batches):
+                ops += [('H', batch), ('G', batch, 0. if i == 0 else 1., 1.)]
+            run(self._V, self._W, self._H, ops + [('W',)], self._backend.new_gradient_accumulator(self._W),
+                sparsity=h_args['sparsity'], eps=self.eps)
+            return None
         local = self._fused('local_gradient_W')
         lateral = h_args['inhibition'] > 0 or h_args['cross_inhibition'] > 0
         if local is not None and not lateral:
@@ -288,6 +330,14 @@ class TransformInvariantNMF:
 
     def _epoch_asg(self, _state, batches, h_args, _lam):
         """Algorithm 5: H and W after every (shuffled) batch (reference :467-472)."""
+        run = self._scheduler(h_args)
+        if run is not None:
+            ops = []
+            for batch in _permuted(batches):
+                ops += [('H', batch), ('G', batch, 0., 1.), ('W',)]
+            run(self._V, self._W, self._H, ops, self._backend.new_gradient_accumulator(self._W),
+                sparsity=h_args['sparsity'], eps=self.eps)
+            return None
         for batch in _permuted(batches):
             self._update_H(batch, **h_args)
             self._update_W(batch)
@@ -296,6 +346,13 @@ class TransformInvariantNMF:
     def _epoch_gsg(self, _state, batches, h_args, _lam):
         """Algorithm 6: H for every shuffled batch, W from the last batch only (reference :474-479)."""
         batch = slice(0, 0)
+        run = self._scheduler(h_args)
+        if run is not None:
+            order = _permuted(batches)
+            ops = [('H', b) for b in order] + [('G', order[-1] if len(order) else batch, 0., 1.), ('W',)]
+            run(self._V, self._W, self._H, ops, self._backend.new_gradient_accumulator(self._W),
+                sparsity=h_args['sparsity'], eps=self.eps)
+            return None
         for batch in _permuted(batches):
             self._update_H(batch, **h_args)
         self._update_W(batch)
@@ -303,6 +360,16 @@ class TransformInvariantNMF:
 
     def _epoch_asag(self, state, batches, h_args, lam):
         """Algorithm 7: running average of the W gradient over batches AND epochs (reference :481-491)."""
+        run = self._scheduler(h_args)
+        if run is not None:
+            first = state is None
+            acc = self._backend.new_gradient_accumulator(self._W) if first else state
+            ops = []
+            for batch in _permuted(batches):
+                ops += [('H', batch), ('G', batch) + self._blend_coefficients(first, lam), ('W',)]
+                first = False
+            run(self._V, self._W, self._H, ops, acc, sparsity=h_args['sparsity'], eps=self.eps)
+            return acc if len(ops) else state
         for batch in _permuted(batches):
             self._update_H(batch, **h_args)
             state = self._blend_gradient_W(state, lam, batch)
@@ -312,6 +379,15 @@ class TransformInvariantNMF:
     def _epoch_gsag(self, state, batches, h_args, lam):
         """Algorithm 8: H for every batch, averaged gradient refreshed from the last one (reference :493-504)."""
         batch = slice(0, 0)
+        run = self._scheduler(h_args)
+        if run is not None:
+            first = state is None
+            acc = self._backend.new_gradient_accumulator(self._W) if first else state
+            order = _permuted(batches)
+            ops = [('H', b) for b in order]
+            ops += [('G', order[-1] if len(order) else batch) + self._blend_coefficients(first, lam), ('W',)]
+            run(self._V, self._W, self._H, ops, acc, sparsity=h_args['sparsity'], eps=self.eps)
+            return acc
         for batch in _permuted(batches):
             self._update_H(batch, **h_args)
         state = self._blend_gradient_W(state, lam, batch)

@@ -22,7 +22,7 @@ EXPORTS = (
     'tnmf_hip_pad_H', 'tnmf_hip_fold_H', 'tnmf_hip_ctx_set_cache', 'tnmf_hip_ctx_invalidate',
     'tnmf_hip_ctx_set_split', 'tnmf_hip_ctx_h_row_stride', 'tnmf_hip_ctx_bind',
     'tnmf_hip_ctx_cache_counters', 'tnmf_hip_sum_parts',
-    'tnmf_hip_update_H_ex',
+    'tnmf_hip_update_H_ex', 'tnmf_hip_run_schedule',
 )
 
 MODES = {'valid': 0, 'full': 1, 'circular': 2, 'reflect': 3}
@@ -36,6 +36,14 @@ class Geom(ctypes.Structure):
                 ('D', ctypes.c_int * 2), ('A', ctypes.c_int * 2), ('dtype', ctypes.c_int),
                 ('h_row_stride', ctypes.c_int)]
 
+
+class Op(ctypes.Structure):
+    """tnmf_hip_op"""
+    _fields_ = [('kind', ctypes.c_int), ('n0', ctypes.c_int), ('n1', ctypes.c_int), ('a', ctypes.c_double),
+                ('b', ctypes.c_double)]
+
+
+OP_UPDATE_H, OP_GRAD_W, OP_APPLY_W = 0, 1, 2
 
 E_STRIDE = -6   # TNMF_E_STRIDE: the kernel family of this call wants C-contiguous H
 
@@ -90,6 +98,7 @@ def load() -> ctypes.CDLL:
     lib.tnmf_hip_update_H.argtypes = [vp, gp, vp, vp, vp, vp, ci, cd, cd, vp]
     lib.tnmf_hip_update_H_ex.argtypes = [vp, gp, ci, vp, vp, vp, vp, cd, cd, cd, cd, ctypes.POINTER(cd), ci,
                                          ctypes.POINTER(cd), ci, vp]
+    lib.tnmf_hip_run_schedule.argtypes = [vp, gp, vp, vp, vp, vp, vp, ctypes.POINTER(Op), ci, cd, cd, vp]
     lib.tnmf_hip_grad_W_fused.argtypes = [vp, gp, vp, vp, vp, vp, ci, vp, vp]
     lib.tnmf_hip_apply_W.argtypes = [vp, gp, vp, vp, cd, vp]
     lib.tnmf_hip_sum_parts.argtypes = [vp, ci, vp, ci, sz, vp, vp]

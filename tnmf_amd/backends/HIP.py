@@ -585,6 +585,51 @@ class HIP_Backend(Backend):
         else:
             self._note_H_cache(Hs, W)
 
+    # -- a whole mini-batch epoch in one call -------------------------------------------------------------------
+    @property
+    def supports_schedules(self) -> bool:
+        """tnmf_hip_run_schedule covers 'valid' mode on one device (with several ranks the W gradient must cross the
+        collective between two of its operations)."""
+        return self._mode == 0 and self._world == 1
+
+    def prefers_schedule(self, H: torch.Tensor) -> bool:
+        """A whole problem this small is bound by launch latency (BASELINE config 1: 0.34 ms per iteration for 0.1 ms of
+        kernels): its full-batch iterations go through run_schedule, i.e. the persistent schedule kernel."""
+        return self.supports_schedules and H.shape[0] > 0 and H.numel() <= (1 << 18)
+
+    def new_gradient_accumulator(self, W: torch.Tensor) -> torch.Tensor:
+        return torch.empty((2,) + tuple(W.shape), dtype=W.dtype, device=W.device)
+
+    def run_schedule(self, V, W: torch.Tensor, H: torch.Tensor, ops, acc: torch.Tensor, sparsity: float = 0.,
+                     eps: float = 1e-9) -> None:
+        """ops: sequence of ('H', slice) | ('G', slice, a, b) | ('W',) -- H half step on the slice, acc = a * acc +
+        b * gradient_W(slice), W update from acc (reference: TransformInvariantNMF.py:444-504) -- issued by ONE call of
+        the library (tnmf_hip_run_schedule): no interpreter time and no host round trip between the batch steps."""
+        assert self.supports_schedules
+        self._check_W(W)
+        self._check_H(H, W.shape[0])
+        ld = self._row_stride(H)
+        assert ld is not None and H.shape[0] == self.n_local_samples
+        assert acc.is_contiguous() and tuple(acc.shape) == (2,) + tuple(W.shape)
+        arr = (_lib.Op * max(1, len(ops)))()
+        for i, op in enumerate(ops):
+            if op[0] == 'W':
+                arr[i].kind, arr[i].n0, arr[i].n1 = _lib.OP_APPLY_W, 0, 0
+                continue
+            sl = self._local(op[1])
+            arr[i].n0, arr[i].n1 = sl.start, sl.stop
+            if op[0] == 'H':
+                arr[i].kind = _lib.OP_UPDATE_H
+            else:
+                arr[i].kind, arr[i].a, arr[i].b = _lib.OP_GRAD_W, float(op[2]), float(op[3])
+        self._validate_H_cache(H, W)
+        with self._timed('schedule'):
+            _lib.check(self._lib.tnmf_hip_run_schedule(
+                self._ctx, ctypes.byref(self._geom(H.shape[0], W.shape[0], ld)), _ptr(self._V_dev), _ptr(W), _ptr(H),
+                _ptr(self._R_scratch), _ptr(acc), arr, len(ops), float(eps), float(sparsity), self._stream()),
+                'tnmf_hip_run_schedule')
+        self._note_H_cache(H, W)
+
     def apply_W(self, W: torch.Tensor, negpos: torch.Tensor, eps: float = 1e-9) -> None:
         """W = W * neg / (pos + eps), then normalise over the atom axes (TransformInvariantNMF.py:232-238)."""
         self._check_W(W)

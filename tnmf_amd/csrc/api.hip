@@ -104,15 +104,16 @@ enum Prim { kReconstruct, kCorrW, kCorrH };
 // covers the shape; chosen by TNMF_PATH_AUTO for float32 problems that are not tiny (the family costs ~20 launches per iteration).
 // Measured: W, H and the energy stay as close to the float64 oracle as with the direct kernels alone,
 // because the H gradient -- the only place where float32 transform error matters -- stays on the direct kernels.
-// A mini-batch slice of the bound activations (tnmf_hip_ctx_bind) follows the family of the resident problem: its H has
-// the resident problem's row stride, and its spectra live in the resident problem's cache.
-bool use_fft_hybrid(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H = nullptr) {
+// A mini-batch slice decides by its OWN size: small batches of a large resident problem (the stochastic schedules with
+// batch_size 3) take the direct kernels -- 6 launches per batch step instead of ~40 -- and find the resident problem's
+// row-padded H readable there: the generic kernels and the split kernel take the row stride, only the f32 MFMA kernels
+// want C-contiguous rows and are skipped for padded ones.
+bool use_fft_hybrid(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
     if (ctx->path == TNMF_PATH_HYBRID) return fft_has(g, dtype);
     if (ctx->path != TNMF_PATH_AUTO || dtype != 0 || !fft_has(g, dtype)) return false;
     // measured crossover against the direct kernels at 128x128 samples, 16 atoms: one sample (2^18 entries) is a tie,
     // two are 20 % ahead, 64 samples (config 2) 1.9x
-    const int n = H ? fft_bound_samples(ctx, g, dtype, H) : g.N;
-    return (size_t)n * g.M * g.Hy * g.Hx >= ((size_t)1 << 19);
+    return (size_t)g.N * g.M * g.Hy * g.Hx >= ((size_t)1 << 19);
 }
 
 // H gradient on the bf16 matrix cores with exact 3 x bf16 operand splits: forced by TNMF_PATH_SPLIT, default under AUTO
@@ -120,6 +121,9 @@ bool use_fft_hybrid(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void
 bool use_split(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
     if (ctx->path == TNMF_PATH_SPLIT) return split_has_corr_W(g, dtype);
     if (ctx->path != TNMF_PATH_AUTO && ctx->path != TNMF_PATH_HYBRID) return false;
+    // (tiny calls -- the batches of the stochastic schedules -- are launch latency: the split kernel needs an operand
+    // preparation launch in front of it, the generic kernel does not)
+    if (ctx->path == TNMF_PATH_AUTO && (size_t)g.N * g.M * g.Hy * g.Hx < ((size_t)1 << 16)) return false;
     return ctx->split && split_has_corr_W(g, dtype);
 }
 
@@ -152,17 +156,17 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
 int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
     // the FFT family serves non-negative factorisations: outputs that are non-negative by construction are clamped
-    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype, H)) {
+    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype)) {
         const int rc = fft_reconstruct(ctx, g, dtype, W, H, R, true, s);
         // AUTO only chose the family for speed: when its workspace does not fit, the direct kernels still do the job
         if (!(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
     }
-    if (g.Hs != g.Hx) return TNMF_E_STRIDE;   // the direct families read C-contiguous H
-    if (use_mfma(ctx, g, dtype, kReconstruct)) {
+    // (the f32 MFMA kernels read C-contiguous H; the generic kernels take the row stride)
+    if (g.Hs == g.Hx && use_mfma(ctx, g, dtype, kReconstruct)) {
         ctx->last_path = "mfma";
         return mfma_reconstruct(ctx, g, (const float *)W, (const float *)H, (float *)R, s);
     }
-    if (ctx->path == TNMF_PATH_MFMA) return TNMF_E_UNSUPPORTED;
+    if (ctx->path == TNMF_PATH_MFMA) return g.Hs != g.Hx ? TNMF_E_STRIDE : TNMF_E_UNSUPPORTED;
     ctx->last_path = "generic";
     return generic_reconstruct(ctx, g, dtype, W, H, R, s);
 }
@@ -186,16 +190,34 @@ int do_corr_W(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const v
         if (rc == TNMF_OK) ctx->last_path = "split";
         if (rc != TNMF_E_UNSUPPORTED) return rc;
     }
-    if (fused && g.Hs != g.Hx) return TNMF_E_STRIDE;   // (nothing has been written yet)
-    if (use_mfma(ctx, g, dtype, kCorrW)) {
+    if ((!fused || g.Hs == g.Hx) && use_mfma(ctx, g, dtype, kCorrW)) {
         if (extra) return TNMF_E_UNSUPPORTED;   // (the f32 MFMA kernel has no extra-term epilogue)
         ctx->last_path = "mfma";
         return mfma_corr_W(ctx, g, (const float *)V, (const float *)R, (const float *)W, (float *)Hio, (float *)neg,
                            (float *)pos, fused, (float)reg, s);
     }
-    if (ctx->path == TNMF_PATH_MFMA || ctx->path == TNMF_PATH_SPLIT) return TNMF_E_UNSUPPORTED;
+    if (ctx->path == TNMF_PATH_MFMA || ctx->path == TNMF_PATH_SPLIT)
+        return fused && g.Hs != g.Hx ? TNMF_E_STRIDE : TNMF_E_UNSUPPORTED;   // (nothing has been written)
     ctx->last_path = "generic";
     return generic_corr_W(ctx, g, dtype, V, R, W, Hio, neg, pos, fused, reg, s, extra);
+}
+
+// the split-K kernel of the direct families alone: partials[P][M*C][Ay*Ax][2] (doubles), P returned.  g.N > 0.
+int do_corr_H_partials(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, const void *R, const void *H,
+                       double *partials, int *P_out, hipStream_t s) {
+    if (g.Hs == g.Hx && use_mfma(ctx, g, dtype, kCorrH)) {
+        ctx->last_path = "mfma";
+        *P_out = mfma_corr_H_chunks(ctx, g);
+        return mfma_corr_H(ctx, g, (const float *)V, (const float *)R, (const float *)H, partials, *P_out, s);
+    }
+    if (ctx->path == TNMF_PATH_MFMA) return g.Hs != g.Hx ? TNMF_E_STRIDE : TNMF_E_UNSUPPORTED;
+    ctx->last_path = "generic";
+    *P_out = generic_corr_H_chunks(ctx, g);
+    return generic_corr_H(ctx, g, dtype, V, R, H, partials, *P_out, s);
+}
+
+bool corr_H_on_fft(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
+    return ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype);
 }
 
 int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, const void *V, const void *R,
@@ -208,21 +230,11 @@ int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, con
         TNMF_HIP_TRY(hipMemsetAsync(pos, 0, (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype), s));
         return TNMF_OK;
     }
-    if (ctx->path == TNMF_PATH_FFT || use_fft_hybrid(ctx, g, dtype, H)) {
+    if (corr_H_on_fft(ctx, g, dtype)) {
         const int rc = fft_grad_W(ctx, g, dtype, V, R, H, neg, pos, true, s);
         if (!(rc == TNMF_E_WORKSPACE && ctx->path == TNMF_PATH_AUTO)) return rc;
     }
-    if (g.Hs != g.Hx) return TNMF_E_STRIDE;
-    if (use_mfma(ctx, g, dtype, kCorrH)) {
-        ctx->last_path = "mfma";
-        P = mfma_corr_H_chunks(ctx, g);
-        CHECK(mfma_corr_H(ctx, g, (const float *)V, (const float *)R, (const float *)H, partials, P, s));
-    } else {
-        if (ctx->path == TNMF_PATH_MFMA) return TNMF_E_UNSUPPORTED;
-        ctx->last_path = "generic";
-        P = generic_corr_H_chunks(ctx, g);
-        CHECK(generic_corr_H(ctx, g, dtype, V, R, H, partials, P, s));
-    }
+    CHECK(do_corr_H_partials(ctx, g, dtype, V, R, H, partials, &P, s));
     return finalize_corr_H(g, dtype, partials, P, neg, pos, s);
 }
 
@@ -592,6 +604,101 @@ int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
     char *np = static_cast<char *>(negpos);
     const size_t wbytes = (size_t)g.M * g.C * g.Ay * g.Ax * esize(dtype);
     return do_corr_H(ctx, g, dtype, sc, V, Rs, H, np, np + wbytes, s);
+}
+
+int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, void *W_inout, void *H_inout,
+                          void *R_scratch, void *acc, const tnmf_hip_op *ops, int n_ops, double eps, double sparsity,
+                          void *stream) {
+    ENTER(ctx, geom);
+    if (n_ops < 0 || (n_ops > 0 && !ops)) return TNMF_E_NULL;
+    if (!V || !W_inout || !H_inout || !acc) return TNMF_E_NULL;
+    const size_t es = esize(dtype);
+    const size_t vs = (size_t)g.C * g.Dy * g.Dx * es, hs = (size_t)g.M * g.Hy * g.Hs * es;
+    const size_t wn = (size_t)g.M * g.C * g.Ay * g.Ax;
+    // scratch for the largest slice of the list: R of the slice (unless the caller brought one), split-K partials, and the
+    // gradient of one batch behind them
+    int nmax = 1;
+    for (int i = 0; i < n_ops; ++i) {
+        if (ops[i].n0 < 0 || ops[i].n1 < ops[i].n0 || ops[i].n1 > g.N) return TNMF_E_GEOM;
+        if (ops[i].n1 - ops[i].n0 > nmax) nmax = ops[i].n1 - ops[i].n0;
+    }
+    double reg = eps;
+    if (sparsity > 0) reg += sparsity;  // TransformInvariantNMF.py:227-230
+    // A whole problem that is tiny (BASELINE config 1): every kernel would run for a few microseconds and the list would be
+    // launch latency -- the persistent schedule kernel walks it in ONE launch.  (Small batches of a LARGE problem stay on
+    // the per-operation path below: measured on the reference's mini-batch geometry, 768 x 1 x 32 x 32 with batch_size 3,
+    // the grid barriers of the persistent kernel -- agent-scope release / acquire across eight L2s -- cost as much as
+    // the launches they replace: 28.5 ms per ASG epoch against 26.7 ms.)
+    (void)nmax;
+    const bool tiny = (size_t)g.N * g.M * g.Hy * g.Hx <= ((size_t)1 << 18);
+    if (n_ops > 0 && tiny && (ctx->path == TNMF_PATH_AUTO || ctx->path == TNMF_PATH_GENERIC) &&
+        generic_schedule_fits(ctx, g, dtype)) {
+        const int P = generic_schedule_chunks(ctx, g);
+        const size_t r_bytes = R_scratch ? 0 : align_up((size_t)g.N * vs, 256);
+        const size_t p_bytes = align_up((size_t)P * wn * 2 * sizeof(double), 256);
+        const size_t o_bytes = align_up((size_t)n_ops * sizeof(tnmf_hip_op), 256);
+        CHECK(ensure_scratch(ctx, r_bytes + p_bytes + o_bytes + 512));
+        void *Rs = R_scratch ? R_scratch : static_cast<void *>(ws_at(ctx, 0));
+        double *partials = reinterpret_cast<double *>(ws_at(ctx, r_bytes));
+        tnmf_hip_op *ops_dev = reinterpret_cast<tnmf_hip_op *>(ws_at(ctx, r_bytes + p_bytes));
+        unsigned *counter = reinterpret_cast<unsigned *>(ws_at(ctx, r_bytes + p_bytes + o_bytes));
+        TNMF_HIP_TRY(hipMemcpyAsync(ops_dev, ops, (size_t)n_ops * sizeof(tnmf_hip_op), hipMemcpyHostToDevice, s));
+        fft_invalidate(ctx);   // H and W change under the family's caches
+        ctx->last_path = "generic";
+        return generic_run_schedule(ctx, g, dtype, V, W_inout, H_inout, Rs, acc, partials, P, ops_dev, n_ops, reg, eps,
+                                    counter, s);
+    }
+    Geo gmax = g;
+    gmax.N = nmax;
+    const Scratch scm = plan_scratch(ctx, gmax, dtype);
+    const size_t grad_off = scm.total;
+    CHECK(ensure_scratch(ctx, scm.total + align_up(2 * wn * es, 256)));
+    char *grad = ws_at(ctx, grad_off);
+    for (int i = 0; i < n_ops; ++i) {
+        const tnmf_hip_op &op = ops[i];
+        Geo gs = g;
+        gs.N = op.n1 - op.n0;
+        const char *Vb = static_cast<const char *>(V) + (size_t)op.n0 * vs;
+        char *Hb = static_cast<char *>(H_inout) + (size_t)op.n0 * hs;
+        void *Rb = R_scratch ? static_cast<void *>(static_cast<char *>(R_scratch) + (size_t)op.n0 * vs)
+                             : static_cast<void *>(ws_at(ctx, scm.r_off));
+        switch (op.kind) {
+            case TNMF_OP_UPDATE_H:
+                if (gs.N == 0) break;
+                CHECK(do_reconstruct(ctx, gs, dtype, W_inout, Hb, Rb, s));
+                CHECK(do_corr_W(ctx, gs, dtype, Vb, Rb, W_inout, Hb, nullptr, nullptr, true, reg, s));
+                break;
+            case TNMF_OP_GRAD_W: {
+                // (the partials of the slice live where plan_scratch(gmax) put them: sized for the largest slice)
+                Scratch sc = plan_scratch(ctx, gs, dtype);
+                sc.part_off = scm.part_off;
+                if (gs.N > 0) CHECK(do_reconstruct(ctx, gs, dtype, W_inout, Hb, Rb, s));
+                if (gs.N > 0 && !corr_H_on_fft(ctx, gs, dtype)) {
+                    // direct kernels: split-K partials, then ONE launch for their fixed-order sum, the blend into the
+                    // accumulator and -- when the W update is the next operation -- that update as well
+                    int P = 1;
+                    double *partials = reinterpret_cast<double *>(ws_at(ctx, scm.part_off));
+                    CHECK(do_corr_H_partials(ctx, gs, dtype, Vb, Rb, Hb, partials, &P, s));
+                    const bool apply_now = i + 1 < n_ops && ops[i + 1].kind == TNMF_OP_APPLY_W;
+                    if (apply_now) fft_invalidate_W(ctx);
+                    CHECK(launch_finalize_blend_apply(g, dtype, partials, P, acc, op.a, op.b, apply_now, W_inout, eps, s));
+                    if (apply_now) ++i;
+                    break;
+                }
+                CHECK(do_corr_H(ctx, gs, dtype, sc, Vb, Rb, Hb, grad, grad + wn * es, s));
+                CHECK(launch_axpby(ctx, dtype, acc, grad, op.a, op.b, 2 * wn, s));
+                break;
+            }
+            case TNMF_OP_APPLY_W: {
+                fft_invalidate_W(ctx);
+                char *np = static_cast<char *>(acc);
+                CHECK(launch_apply_normalize_W(g, dtype, W_inout, np, np + wn * es, eps, true, s));
+                break;
+            }
+            default: return TNMF_E_UNSUPPORTED;
+        }
+    }
+    return TNMF_OK;
 }
 
 int tnmf_hip_sum_parts(tnmf_hip_ctx *ctx, int dtype, const void *parts, int n_parts, size_t n_elems, void *out,

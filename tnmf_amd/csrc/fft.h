@@ -74,9 +74,6 @@ void fft_invalidate_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H)
 void fft_bind(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H, const void *V);
 void fft_unbind(tnmf_hip_ctx *ctx);
 void fft_invalidate_W(tnmf_hip_ctx *ctx);   // the dictionary has changed: its cached spectra are stale
-// samples of the resident problem a call on (g, H) belongs to: the bound sample count when H is a slice of the explicitly
-// bound activations, g.N otherwise (the dispatch decides the kernel family by the resident problem, not by the slice)
-int fft_bound_samples(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H);
 void fft_release(tnmf_hip_ctx *ctx);
 // pre-size the family's workspace for `g` (with_window: including the buffers of the fused FFT H update)
 int fft_reserve(tnmf_hip_ctx *ctx, const Geo &g, int dtype, bool with_window);

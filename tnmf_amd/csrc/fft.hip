@@ -529,16 +529,6 @@ void fft_unbind(tnmf_hip_ctx *ctx) {
     f.SV_ok.clear();
 }
 
-int fft_bound_samples(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
-    const FftState &f = ctx->fft;
-    if (!f.cache_enabled || !f.bound || !f.explicit_bind || dtype != f.dtype || !same_shape(f.geo, g) || !H || !f.H_base)
-        return g.N;
-    const size_t hb = (size_t)g.M * g.Hy * g.Hs * esz_of(dtype);
-    const ptrdiff_t d = static_cast<const char *>(H) - static_cast<const char *>(f.H_base);
-    if (d < 0 || (size_t)d % hb || (long)((size_t)d / hb) + g.N > f.geo.N) return g.N;
-    return f.geo.N;
-}
-
 void fft_invalidate_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H) {
     FftState &f = ctx->fft;
     const Slot sl = locate(f, g, dtype, H, nullptr);

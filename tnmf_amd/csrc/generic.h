@@ -21,6 +21,8 @@ int finalize_corr_H(const Geo &g, int dtype, const double *partials, int P, void
 
 int launch_mu_update(const tnmf_hip_ctx *ctx, int dtype, void *arr, const void *neg, void *pos, double reg, size_t n,
                      hipStream_t s);
+int launch_axpby(const tnmf_hip_ctx *ctx, int dtype, void *acc, const void *g, double a, double b, size_t n,
+                 hipStream_t s);
 int launch_sum_parts(const tnmf_hip_ctx *ctx, int dtype, const void *parts, int n_parts, size_t n, void *out,
                      hipStream_t s);
 int launch_apply_normalize_W(const Geo &g, int dtype, void *W, const void *neg, void *pos, double eps, bool apply,
@@ -44,3 +46,16 @@ int launch_mu_update_extra(const tnmf_hip_ctx *ctx, int dtype, void *H, const vo
 // modes: H[N][M][Sy][Sx] = H * fold(negp) / (fold(posp) + E + reg), negp / posp on the padded shape (g.Hy, g.Hx)
 int launch_fold_update(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, int mode, int Sy, int Sx, void *H,
                        const void *negp, const void *posp, const void *E, double reg, hipStream_t s);
+
+// the persistent schedule kernel (k_schedule): a whole operation list of tnmf_hip_run_schedule in one launch, on the generic
+// kernels' device functions.  ops_dev: the operations in DEVICE memory; partials: P * M * C * Ay * Ax * 2 doubles;
+// counter: one zero-initialisable word; R: [g.N, C, *D] (every sample's own slot)
+bool generic_schedule_fits(const tnmf_hip_ctx *ctx, const Geo &g, int dtype);
+int generic_schedule_chunks(const tnmf_hip_ctx *ctx, const Geo &g);
+int generic_run_schedule(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, void *W, void *H, void *R, void *acc,
+                         double *partials, int P, const tnmf_hip_op *ops_dev, int n_ops, double reg, double eps,
+                         unsigned *counter, hipStream_t s);
+// mini-batch step behind the split-K kernel: acc = a * acc + b * (fixed-order sum of the partials), then optionally the W
+// update from acc (W = W * acc_neg / (acc_pos + eps), normalised) -- one launch
+int launch_finalize_blend_apply(const Geo &g, int dtype, const double *partials, int P, void *acc, double a, double b,
+                                bool apply, void *W, double eps, hipStream_t s);

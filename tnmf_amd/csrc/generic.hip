@@ -37,16 +37,16 @@ inline Tile make_tile(int rows, int cols) {
 // ------------------------------------------------------------------------------------------------------------
 // reconstruct: one block = one (n, c, output tile); loop over atoms, H tile + halo and flipped W[m,c] in LDS.
 // ------------------------------------------------------------------------------------------------------------
+// (the bodies are device functions of a block index: the __global__ kernels below launch one workgroup per block, the
+// persistent schedule kernel at the end of this file walks the blocks of one phase after the other)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_reconstruct(Geo g, Tile t, const T *__restrict__ W,
-                                                        const T *__restrict__ H, T *__restrict__ R) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void reconstruct_block(const Geo &g, const Tile &t, unsigned bid, const T *__restrict__ W,
+                                                  const T *__restrict__ H, T *__restrict__ R, unsigned char *smem_raw) {
     T *Hs = reinterpret_cast<T *>(smem_raw);
     const int SH = t.TY + g.Ay - 1, SW = t.TX + g.Ax - 1;
     const int nA = g.Ay * g.Ax;
     T *Ws = Hs + SH * SW;
 
-    unsigned bid = blockIdx.x;
     const int txi = bid % t.tiles_x;
     bid /= t.tiles_x;
     const int tyi = bid % t.tiles_y;
@@ -59,13 +59,13 @@ __global__ __launch_bounds__(kBlock) void k_reconstruct(Geo g, Tile t, const T *
 
     T acc = T(0);
     for (int m = 0; m < g.M; ++m) {
-        const T *h = H + ((size_t)n * g.M + m) * g.Hy * g.Hx;
+        const T *h = H + ((size_t)n * g.M + m) * g.Hy * g.Hs;   // (rows of H may be padded: g.Hs >= g.Hx)
         const T *w = W + ((size_t)m * g.C + c) * nA;
         __syncthreads();
         for (int i = threadIdx.x; i < SH * SW; i += kBlock) {
             const int r = i / SW, q = i - r * SW;
             const int hy = y0 + r, hx = x0 + q;
-            Hs[i] = (hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hx + hx] : T(0);
+            Hs[i] = (hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hs + hx] : T(0);
         }
         for (int i = threadIdx.x; i < nA; i += kBlock) Ws[i] = w[nA - 1 - i];  // flipped atom
         __syncthreads();
@@ -79,23 +79,28 @@ __global__ __launch_bounds__(kBlock) void k_reconstruct(Geo g, Tile t, const T *
     if (y < g.Dy && x < g.Dx) R[(((size_t)n * g.C + c) * g.Dy + y) * g.Dx + x] = acc;
 }
 
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reconstruct(Geo g, Tile t, const T *__restrict__ W,
+                                                        const T *__restrict__ H, T *__restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    reconstruct_block<T>(g, t, blockIdx.x, W, H, R, smem_raw);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // corr_W (H gradient): one block = one (n, m, tile of the shift plane); loop over channels, zero-padded V and R
 // tiles in LDS.  FUSED: H = (H * neg) / (pos + reg) in place instead of writing neg/pos.
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_corr_W(Geo g, Tile t, const T *__restrict__ V, const T *__restrict__ Rr,
-                                                   const T *__restrict__ W, T *__restrict__ Hio,
-                                                   T *__restrict__ neg, T *__restrict__ pos, T reg,
-                                                   const T *__restrict__ extra) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void corr_W_block(const Geo &g, const Tile &t, unsigned bid, const T *__restrict__ V,
+                                             const T *__restrict__ Rr, const T *__restrict__ W, T *__restrict__ Hio,
+                                             T *__restrict__ neg, T *__restrict__ pos, T reg,
+                                             const T *__restrict__ extra, unsigned char *smem_raw) {
     const int SH = t.TY + g.Ay - 1, SW = t.TX + g.Ax - 1;
     const int nA = g.Ay * g.Ax;
     T *Vs = reinterpret_cast<T *>(smem_raw);
     T *Rs = Vs + SH * SW;
     T *Ws = Rs + SH * SW;
 
-    unsigned bid = blockIdx.x;
     const int txi = bid % t.tiles_x;
     bid /= t.tiles_x;
     const int tyi = bid % t.tiles_y;
@@ -136,14 +141,24 @@ __global__ __launch_bounds__(kBlock) void k_corr_W(Geo g, Tile t, const T *__res
     if (u < g.Hy && vv < g.Hx) {
         const size_t o = (((size_t)n * g.M + m) * g.Hy + u) * g.Hx + vv;
         if (FUSED) {
-            const T h = Hio[o];
-            if (extra) ap += extra[o];   // lateral inhibition terms (TransformInvariantNMF.py:253-269)
-            Hio[o] = (h * an) / (ap + reg);
+            const size_t oh = (((size_t)n * g.M + m) * g.Hy + u) * g.Hs + vv;   // (rows of H may be padded)
+            const T h = Hio[oh];
+            if (extra) ap += extra[oh];   // lateral inhibition terms (TransformInvariantNMF.py:253-269), laid out like H
+            Hio[oh] = (h * an) / (ap + reg);
         } else {
             neg[o] = an;
             pos[o] = ap;
         }
     }
+}
+
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_corr_W(Geo g, Tile t, const T *__restrict__ V, const T *__restrict__ Rr,
+                                                   const T *__restrict__ W, T *__restrict__ Hio,
+                                                   T *__restrict__ neg, T *__restrict__ pos, T reg,
+                                                   const T *__restrict__ extra) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    corr_W_block<T, FUSED>(g, t, blockIdx.x, V, Rr, W, Hio, neg, pos, reg, extra, smem_raw);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -154,10 +169,9 @@ __global__ __launch_bounds__(kBlock) void k_corr_W(Geo g, Tile t, const T *__res
 constexpr int kMaxShiftsPerThread = 4;  // atoms up to 4 * 256 = 1024 shifts (e.g. 32 x 32)
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_corr_H(Geo g, Tile t, int P, const T *__restrict__ V,
-                                                   const T *__restrict__ Rr, const T *__restrict__ H,
-                                                   double *__restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void corr_H_block(const Geo &g, const Tile &t, int P, int p, int mc, const T *__restrict__ V,
+                                             const T *__restrict__ Rr, const T *__restrict__ H,
+                                             double *__restrict__ partials, unsigned char *smem_raw) {
     const int SH = t.TY + g.Ay - 1, SW = t.TX + g.Ax - 1;
     const int nA = g.Ay * g.Ax;
     const int npix = t.TY * t.TX;
@@ -165,8 +179,6 @@ __global__ __launch_bounds__(kBlock) void k_corr_H(Geo g, Tile t, int P, const T
     T *Vs = Hs + SH * SW;
     T *Rs = Vs + npix;
 
-    const int p = blockIdx.x;
-    const int mc = blockIdx.y;
     const int m = mc / g.C, c = mc % g.C;
 
     const int gs = nA < kBlock ? nA : kBlock;  // threads per group = shifts handled side by side
@@ -186,14 +198,14 @@ __global__ __launch_bounds__(kBlock) void k_corr_H(Geo g, Tile t, int P, const T
         const int tyi = r % t.tiles_y;
         const int n = r / t.tiles_y;
         const int y0 = tyi * t.TY, x0 = txi * t.TX;
-        const T *h = H + ((size_t)n * g.M + m) * g.Hy * g.Hx;
+        const T *h = H + ((size_t)n * g.M + m) * g.Hy * g.Hs;   // (rows of H may be padded: g.Hs >= g.Hx)
         const T *v = V + ((size_t)n * g.C + c) * g.Dy * g.Dx;
         const T *rr = Rr + ((size_t)n * g.C + c) * g.Dy * g.Dx;
         __syncthreads();
         for (int i = threadIdx.x; i < SH * SW; i += kBlock) {
             const int a = i / SW, q = i - a * SW;
             const int hy = y0 + a, hx = x0 + q;
-            Hs[i] = (hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hx + hx] : T(0);
+            Hs[i] = (hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hs + hx] : T(0);
         }
         for (int i = threadIdx.x; i < npix; i += kBlock) {
             const int a = i / t.TX, q = i - a * t.TX;
@@ -245,6 +257,14 @@ __global__ __launch_bounds__(kBlock) void k_corr_H(Geo g, Tile t, int P, const T
         out[0] = sn;
         out[1] = sp;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_corr_H(Geo g, Tile t, int P, const T *__restrict__ V,
+                                                   const T *__restrict__ Rr, const T *__restrict__ H,
+                                                   double *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    corr_H_block<T>(g, t, P, blockIdx.x, blockIdx.y, V, Rr, H, partials, smem_raw);
 }
 
 }  // namespace
@@ -315,6 +335,17 @@ __global__ void k_sum_parts(const T *__restrict__ parts, int n_parts, size_t n, 
     }
 }
 
+// acc = a * acc + b * g  (a == 0: acc = b * g, whatever acc held): the gradient accumulators of the mini-batch schedules
+// (TransformInvariantNMF.py:444-455: `acc *= (1 - lambda); acc += lambda * g`, or `acc += g`)
+template <typename T>
+__global__ void k_axpby(T *__restrict__ acc, const T *__restrict__ g, T a, T b, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T t = b == T(1) ? g[i] : b * g[i];
+        acc[i] = a == T(0) ? t : (a == T(1) ? acc[i] + t : a * acc[i] + t);
+    }
+}
+
 template <typename T>
 __device__ double block_sum(double v, double *sh) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -330,10 +361,10 @@ __device__ double block_sum(double v, double *sh) {
 
 // W[mc, :] = (W * neg) / (pos + eps) if APPLY, then W[mc, :] /= sum.  One block per (m, c) row.
 template <typename T, bool APPLY>
-__global__ __launch_bounds__(kBlock) void k_apply_normalize_W(int nA, T *__restrict__ W, const T *__restrict__ neg,
-                                                              T *__restrict__ pos, T eps) {
+__device__ __forceinline__ void apply_normalize_row(int nA, unsigned row, T *__restrict__ W, const T *__restrict__ neg,
+                                                    T *__restrict__ pos, T eps) {
     __shared__ double sh[kBlock / 64];
-    const size_t base = (size_t)blockIdx.x * nA;
+    const size_t base = (size_t)row * nA;
     double part = 0.0;
     for (int i = threadIdx.x; i < nA; i += kBlock) {
         T w = W[base + i];
@@ -347,6 +378,150 @@ __global__ __launch_bounds__(kBlock) void k_apply_normalize_W(int nA, T *__restr
     }
     const T tot = (T)block_sum<T>(part, sh);
     for (int i = threadIdx.x; i < nA; i += kBlock) W[base + i] = W[base + i] / tot;
+}
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(kBlock) void k_apply_normalize_W(int nA, T *__restrict__ W, const T *__restrict__ neg,
+                                                              T *__restrict__ pos, T eps) {
+    apply_normalize_row<T, APPLY>(nA, blockIdx.x, W, neg, pos, eps);
+}
+
+// W gradient of a mini-batch step behind the split-K kernel, in one launch: fixed-order sum of the P partials of row
+// (m, c) in double, flip to the reference's orientation, acc = a * acc + b * g, and -- when the W update follows at once
+// (ASG / ASAG: every batch) -- W = W * acc_neg / (acc_pos + eps), normalised.  One workgroup per (m, c) row.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_finalize_blend_apply(int MC, int nA, int P, const double *__restrict__ partials,
+                                                                 T *__restrict__ acc, T ca, T cb, int apply,
+                                                                 T *__restrict__ W, T eps) {
+    const unsigned r = blockIdx.x;
+    const int total = MC * nA;
+    for (int sh = threadIdx.x; sh < nA; sh += kBlock) {
+        const int e = (int)r * nA + sh;
+        double sn = 0.0, sp = 0.0;
+        for (int p = 0; p < P; ++p) {
+            sn += partials[((size_t)p * total + e) * 2 + 0];
+            sp += partials[((size_t)p * total + e) * 2 + 1];
+        }
+        const size_t o = (size_t)r * nA + (nA - 1 - sh);
+        const T gn = (T)sn, gp = (T)sp;
+        const T tn = cb == T(1) ? gn : cb * gn, tp = cb == T(1) ? gp : cb * gp;
+        acc[o] = ca == T(0) ? tn : (ca == T(1) ? acc[o] + tn : ca * acc[o] + tn);
+        acc[total + o] = ca == T(0) ? tp : (ca == T(1) ? acc[total + o] + tp : ca * acc[total + o] + tp);
+    }
+    __syncthreads();
+    if (apply) apply_normalize_row<T, true>(nA, r, W, acc, acc + (size_t)total, eps);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent schedule kernel: a whole list of mini-batch operations (tnmf_hip_run_schedule) in ONE launch.
+//
+// With batch_size 3 a step of the stochastic schedules is eight kernels of a few microseconds each, 256 times per epoch:
+// the epoch is launch latency.  Here the workgroups of one co-resident grid walk the operations themselves: every phase
+// of an operation (reconstruct -> H update;  reconstruct -> W-gradient partials -> fixed-order sum + blend;  W update) is a
+// loop over the blocks the kernels above would have been launched with, and a grid-wide barrier (one atomic counter,
+// agent-scope release / acquire around it) stands where a kernel boundary was.  Same device functions, same arithmetic.
+// Every workgroup executes the same operation list and therefore the same number of barriers: the grid drains.
+// ------------------------------------------------------------------------------------------------------------
+struct SchedArgs {
+    Geo g;                  // the resident problem (g.N = all samples)
+    Tile tR, tW, tH;        // tiles of reconstruct (sample plane), corr_W (shift plane), corr_H (sample plane)
+    const void *V;
+    void *W, *H, *R, *acc;
+    double *partials;
+    const tnmf_hip_op *ops;
+    int n_ops, P;
+    double reg, eps;
+    unsigned *counter;      // zeroed before the launch
+};
+
+// counter[0]: arrivals (monotonic), counter[32]: generation flag on a line of its own.  The last workgroup to arrive
+// publishes the generation; the others poll the flag (plain loads of a line nobody is doing atomics on).  Only the first
+// wave of a workgroup talks to the memory system: __syncthreads() has drained every wave's stores (workgroup-scope
+// release) before it issues the agent-scope release, and its agent-scope acquire invalidates the CU's vector cache for
+// all four waves.
+__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned &target) {
+    __syncthreads();
+    target += gridDim.x;
+    if (threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (threadIdx.x == 0) {
+            const unsigned gen = target / gridDim.x;
+            if (atomicAdd(counter, 1u) + 1u == target) {
+                __hip_atomic_store(counter + 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                while (__hip_atomic_load(counter + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_schedule(SchedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Geo &g = a.g;
+    const int nA = g.Ay * g.Ax, MC = g.M * g.C;
+    const size_t vs = (size_t)g.C * g.Dy * g.Dx, hs = (size_t)g.M * g.Hy * g.Hs;
+    T *W = static_cast<T *>(a.W), *acc = static_cast<T *>(a.acc);
+    unsigned target = 0;
+    for (int i = 0; i < a.n_ops; ++i) {
+        const tnmf_hip_op op = a.ops[i];
+        Geo gs = g;
+        gs.N = op.n1 - op.n0;
+        const T *Vb = static_cast<const T *>(a.V) + (size_t)op.n0 * vs;
+        T *Hb = static_cast<T *>(a.H) + (size_t)op.n0 * hs;
+        T *Rb = static_cast<T *>(a.R) + (size_t)op.n0 * vs;
+        if (op.kind == TNMF_OP_UPDATE_H || op.kind == TNMF_OP_GRAD_W) {
+            const unsigned nb = (unsigned)(gs.N * g.C * a.tR.tiles_y * a.tR.tiles_x);
+            for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) reconstruct_block<T>(gs, a.tR, b, W, Hb, Rb, smem_raw);
+            grid_barrier(a.counter, target);
+        }
+        if (op.kind == TNMF_OP_UPDATE_H) {
+            const unsigned nb = (unsigned)(gs.N * g.M * a.tW.tiles_y * a.tW.tiles_x);
+            for (unsigned b = blockIdx.x; b < nb; b += gridDim.x)
+                corr_W_block<T, true>(gs, a.tW, b, Vb, Rb, W, Hb, (T *)nullptr, (T *)nullptr, (T)a.reg, (const T *)nullptr,
+                                      smem_raw);
+            grid_barrier(a.counter, target);
+        } else if (op.kind == TNMF_OP_GRAD_W) {
+            const int items = gs.N * a.tH.tiles_y * a.tH.tiles_x;
+            const int P = items < a.P ? (items > 0 ? items : 1) : a.P;
+            for (unsigned b = blockIdx.x; b < (unsigned)(P * MC); b += gridDim.x)
+                corr_H_block<T>(gs, a.tH, P, (int)(b % P), (int)(b / P), Vb, Rb, Hb, a.partials, smem_raw);
+            grid_barrier(a.counter, target);
+            // fixed-order sum of the partials (double), flip to the reference's orientation, blend into the accumulator:
+            // one workgroup per (m, c) row -- and when the W update follows immediately (ASG / ASAG: every batch), that
+            // workgroup applies it to its row on the spot: one barrier less per batch step
+            const int total = MC * nA;
+            const bool apply_now = i + 1 < a.n_ops && a.ops[i + 1].kind == TNMF_OP_APPLY_W;
+            for (unsigned r = blockIdx.x; r < (unsigned)MC; r += gridDim.x) {
+                for (int sh = threadIdx.x; sh < nA; sh += kBlock) {
+                    const int e = (int)r * nA + sh;
+                    double sn = 0.0, sp = 0.0;
+                    for (int p = 0; p < P; ++p) {
+                        sn += a.partials[((size_t)p * total + e) * 2 + 0];
+                        sp += a.partials[((size_t)p * total + e) * 2 + 1];
+                    }
+                    const size_t o = (size_t)r * nA + (nA - 1 - sh);
+                    const T gn = (T)sn, gp = (T)sp, ca = (T)op.a, cb = (T)op.b;
+                    const T tn = cb == T(1) ? gn : cb * gn, tp = cb == T(1) ? gp : cb * gp;
+                    acc[o] = ca == T(0) ? tn : (ca == T(1) ? acc[o] + tn : ca * acc[o] + tn);
+                    acc[total + o] = ca == T(0) ? tp : (ca == T(1) ? acc[total + o] + tp : ca * acc[total + o] + tp);
+                }
+                __syncthreads();   // the row of acc is complete (written by this workgroup's own threads)
+                if (apply_now) apply_normalize_row<T, true>(nA, r, W, acc, acc + (size_t)MC * nA, (T)a.eps);
+            }
+            if (apply_now) ++i;    // (the W update has been done)
+            grid_barrier(a.counter, target);
+        } else if (op.kind == TNMF_OP_APPLY_W) {
+            for (unsigned r = blockIdx.x; r < (unsigned)MC; r += gridDim.x) {
+                __syncthreads();   // (the row reduction's shared words are reused row after row)
+                apply_normalize_row<T, true>(nA, r, W, acc, acc + (size_t)MC * nA, (T)a.eps);
+            }
+            grid_barrier(a.counter, target);
+        }
+    }
 }
 
 template <typename T>
@@ -513,6 +688,18 @@ int launch_mu_update(const tnmf_hip_ctx *ctx, int dtype, void *arr, const void *
     return TNMF_OK;
 }
 
+int launch_axpby(const tnmf_hip_ctx *ctx, int dtype, void *acc, const void *g, double a, double b, size_t n,
+                 hipStream_t s) {
+    if (n == 0) return TNMF_OK;
+    const int grid = grid_for(n, ctx);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_axpby<float>, dim3(grid), dim3(kBlock), 0, s, (float *)acc, (const float *)g, (float)a, (float)b, n);
+    else
+        hipLaunchKernelGGL(k_axpby<double>, dim3(grid), dim3(kBlock), 0, s, (double *)acc, (const double *)g, a, b, n);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
 int launch_sum_parts(const tnmf_hip_ctx *ctx, int dtype, const void *parts, int n_parts, size_t n, void *out,
                      hipStream_t s) {
     if (n == 0) return TNMF_OK;
@@ -671,6 +858,86 @@ int launch_pad_fold(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, int mode, 
         if (dtype == 0) LAUNCH_PF(k_pad_H, float); else LAUNCH_PF(k_pad_H, double);
     }
 #undef LAUNCH_PF
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// the persistent schedule kernel (see k_schedule)
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+size_t schedule_lds(const Geo &g, const Tile &tR, const Tile &tW, const Tile &tH) {
+    const size_t nA = (size_t)g.Ay * g.Ax;
+    const size_t r = ((size_t)(tR.TY + g.Ay - 1) * (tR.TX + g.Ax - 1) + nA) * sizeof(T);
+    const size_t w = (2 * (size_t)(tW.TY + g.Ay - 1) * (tW.TX + g.Ax - 1) + nA) * sizeof(T);
+    size_t h = ((size_t)(tH.TY + g.Ay - 1) * (tH.TX + g.Ax - 1) + 2 * (size_t)tH.TY * tH.TX) * sizeof(T);
+    const int gs = nA < (size_t)kBlock ? (int)nA : kBlock;
+    const size_t red = (size_t)(kBlock / gs) * nA * 2 * sizeof(double);
+    if (red > h) h = red;
+    return r > w ? (r > h ? r : h) : (w > h ? w : h);
+}
+
+}  // namespace
+
+bool generic_schedule_fits(const tnmf_hip_ctx *, const Geo &g, int dtype) {
+    const Tile tR = make_tile(g.Dy, g.Dx), tW = make_tile(g.Hy, g.Hx), tH = make_tile(g.Dy, g.Dx);
+    if (g.Ay * g.Ax > kBlock * kMaxShiftsPerThread) return false;
+    const size_t lds = dtype == 0 ? schedule_lds<float>(g, tR, tW, tH) : schedule_lds<double>(g, tR, tW, tH);
+    return lds <= 64 * 1024;
+}
+
+int generic_schedule_chunks(const tnmf_hip_ctx *ctx, const Geo &g) {
+    // split of the pixel sum of the W gradient: enough (chunk, atom, channel) blocks for the grid, no more
+    const int grid = ctx->num_cu < 128 ? ctx->num_cu : 128;
+    int P = cdiv(grid, g.M * g.C);
+    return P < 1 ? 1 : (P > 64 ? 64 : P);
+}
+
+int generic_run_schedule(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *V, void *W, void *H, void *R, void *acc,
+                         double *partials, int P, const tnmf_hip_op *ops_dev, int n_ops, double reg, double eps,
+                         unsigned *counter, hipStream_t s) {
+    SchedArgs a;
+    a.g = g;
+    a.tR = make_tile(g.Dy, g.Dx);
+    a.tW = make_tile(g.Hy, g.Hx);
+    a.tH = make_tile(g.Dy, g.Dx);
+    a.V = V;
+    a.W = W;
+    a.H = H;
+    a.R = R;
+    a.acc = acc;
+    a.partials = partials;
+    a.ops = ops_dev;
+    a.n_ops = n_ops;
+    a.P = P;
+    a.reg = reg;
+    a.eps = eps;
+    a.counter = counter;
+    const size_t lds = dtype == 0 ? schedule_lds<float>(g, a.tR, a.tW, a.tH) : schedule_lds<double>(g, a.tR, a.tW, a.tH);
+    if (lds > 64 * 1024) return TNMF_E_UNSUPPORTED;
+    // one workgroup per CU at most (4 waves, <= 64 KB of LDS): the whole grid is resident at once, which the barrier needs
+    const int grid = ctx->num_cu < 128 ? ctx->num_cu : 128;
+    TNMF_HIP_TRY(hipMemsetAsync(counter, 0, 64 * sizeof(unsigned), s));
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_schedule<float>, dim3(grid), dim3(kBlock), lds, s, a);
+    else
+        hipLaunchKernelGGL(k_schedule<double>, dim3(grid), dim3(kBlock), lds, s, a);
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int launch_finalize_blend_apply(const Geo &g, int dtype, const double *partials, int P, void *acc, double a, double b,
+                                bool apply, void *W, double eps, hipStream_t s) {
+    const int MC = g.M * g.C, nA = g.Ay * g.Ax;
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_finalize_blend_apply<float>, dim3(MC), dim3(kBlock), 0, s, MC, nA, P, partials, (float *)acc,
+                           (float)a, (float)b, apply ? 1 : 0, (float *)W, (float)eps);
+    else
+        hipLaunchKernelGGL(k_finalize_blend_apply<double>, dim3(MC), dim3(kBlock), 0, s, MC, nA, P, partials, (double *)acc,
+                           a, b, apply ? 1 : 0, (double *)W, eps);
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
 }
