@@ -325,6 +325,11 @@ def main():
     def split_executed_flops():
         """Every bf16 MFMA flop one launch of the split kernel issues (tile padding included): per 8 x 32-pixel tile,
         atom tile and channel, 4 waves x KB k-blocks x 2 rows x (V, R) x 6 products of 32 x 32 x 16."""
+        if k == 1:   # 1-D instantiation: rows of a tile = eight samples, k blocks of 16 taps (atoms padded to 16 / 32 / 64)
+            ax = cfg['A'][0]
+            kb = (4 if ax <= 16 else 8 if ax <= 32 else 16) // 4
+            tiles = -(-n_local // 8) * -(-Hs[0] // 32) * -(-cfg['M'] // 32) * cfg['C']
+            return launch_scale * tiles * 4 * kb * 4 * 6 * (2.0 * 32 * 32 * 16)
         ay, ax = cfg['A']
         kb = (((ay + 1) // 2) * ((ax + 3) // 4) + 1) // 2
         tiles = n_local * -(-Hs[0] // 8) * -(-Hs[1] // 32) * -(-cfg['M'] // 32) * cfg['C']

@@ -577,14 +577,19 @@ ONE_D_SHAPES = [
     (10, 3, (60,), 8, (20,)),
     (2, 1, (500,), 4, (16,)),
     (3, 2, (301,), 5, (7,)),
+    # several row blocks of eight samples with a ragged last one, 40 atoms (a partial second atom tile), 64-tap atoms
+    (19, 3, (200,), 40, (64,)),
+    (9, 1, (77,), 33, (33,)),
+    (4, 2, (150,), 6, (70,)),      # atoms longer than the split kernel takes (64 taps): generic H update
 ]
 
 
 @pytest.mark.parametrize('shape', ONE_D_SHAPES, ids=[f'{s[0]}x{s[1]}x{s[2][0]}_m{s[3]}_a{s[4][0]}' for s in ONE_D_SHAPES])
 def test_one_dimensional_signals_on_the_fft_rows(shape):
     """1-D problems under path='hybrid': reconstruct and the W gradient are pointwise products of row spectra (own LDS
-    FFT kernels, k_mix_reconstruct / k_mix_grad_W_1d), the H update stays on the direct kernels -- against the float64
-    oracle, with the fused half steps chained so that the cached spectra are exercised."""
+    FFT kernels, k_mix_reconstruct / k_mix_grad_W_1d), the H gradient / fused H update run on the bf16 matrix cores -- the
+    split kernel's 1-D instantiation, eight samples per tile, atoms of up to 64 taps -- against the float64 oracle,
+    with the fused half steps chained so that the cached spectra are exercised."""
     N, C, D, M, A = shape
     rng = np.random.default_rng(N * 100 + M)
     V = rng.random((N, C) + D)
@@ -598,8 +603,13 @@ def test_one_dimensional_signals_on_the_fft_rows(shape):
     assert be.last_path == 'fft'
     on, op = orc.gradient_H(V, Wn, Hn, slice(None), 'c')
     neg, pos = be.reconstruction_gradient_H(V, W, H)
-    assert be.last_path == 'generic'
+    assert be.last_path == ('split' if A[0] <= 64 else 'generic')
     assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+    for s in (slice(0, 0), slice(N - 1, N), slice(1, N)):
+        n2, p2 = be.reconstruction_gradient_H(V, W, H, s)
+        assert tuple(n2.shape) == on[s].shape
+        if on[s].size:
+            assert relmax(be.to_ndarray(n2), on[s]) < tol and relmax(be.to_ndarray(p2), op[s]) < tol
     for s in (slice(None), slice(N - 1, N)):
         on, op = orc.gradient_W(V, Wn, Hn, s, 'c')
         neg, pos = be.reconstruction_gradient_W(V, W, H, s)
@@ -609,6 +619,7 @@ def test_one_dimensional_signals_on_the_fft_rows(shape):
     Ho, Wo = Hn.copy(), Wn.copy()
     for _ in range(2):
         be.fused_update_H(V, Wf, Hf, slice(None), sparsity=0., eps=1e-9)
+        assert be.last_path == ('split' if A[0] <= 64 else 'generic')
         be.fused_update_W(V, Wf, Hf, slice(None), eps=1e-9)
         on, op = orc.gradient_H(V, Wo, Ho, slice(None), 'c')
         Ho = Ho * on / (op + 1e-9)

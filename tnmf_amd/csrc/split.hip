@@ -3,7 +3,8 @@
 #include "split.h"
 
 // instantiated (atom rows, runs per atom row = ceil(Ax / 4)) pairs -- keep in step with SPLIT_SHAPES of the Makefile
-#define TNMF_SPLIT_SHAPES(X) X(12, 3) X(9, 3) X(16, 4) X(7, 2) X(8, 2) X(5, 2)
+// (1, n): the 1-D instantiations -- signals with atoms of up to 4 n taps, eight samples per tile
+#define TNMF_SPLIT_SHAPES(X) X(12, 3) X(9, 3) X(16, 4) X(7, 2) X(8, 2) X(5, 2) X(1, 4) X(1, 8) X(1, 16)
 
 #define DECL(AY_, NR4_)                                                                                              \
     int split_launch_##AY_##_##NR4_(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *W, \
@@ -15,7 +16,11 @@ TNMF_SPLIT_SHAPES(DECL)
 
 bool split_has_corr_W(const Geo &g, int dtype) {
     if (dtype != 0) return false;
-    if (g.Dy == 1 || g.Ay == 1) return false;   // 1-D signals: other kernels
+    if (g.Dy == 1 && g.Ay == 1) {
+        // 1-D signals: the rows of a tile are samples; atoms of up to 64 taps
+        return g.Ax <= 64 && g.Dx >= 4 && (size_t)align_up((size_t)g.M, 32) * (size_t)(g.Hs > g.Hx ? g.Hs : g.Hx) * 4 < ((size_t)1 << 31);
+    }
+    if (g.Dy == 1 || g.Ay == 1) return false;   // (a 2-D problem with one-row samples or atoms: other kernels)
     if (g.Ax > 16 || g.Ay > 16 || g.Dx < 4) return false;   // (16-byte window loads need 4 columns)
     // H / neg / pos of one sample are addressed through 32-bit buffer offsets (atom * plane bytes + ...): all the planes
     // of a sample, rounded up to whole atom tiles, must stay below 2^31 bytes or the offsets wrap
@@ -39,7 +44,8 @@ int split_prepare_device() {
 
 int split_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *W, float *H_inout,
                  float *neg, float *pos, bool fused, float reg, hipStream_t s, const float *extra) {
-    const int nr4 = (g.Ax + 3) / 4;
+    int nr4 = (g.Ax + 3) / 4;
+    if (g.Dy == 1 && g.Ay == 1) nr4 = g.Ax <= 16 ? 4 : (g.Ax <= 32 ? 8 : 16);   // 1-D: whole k blocks of 16 taps
 #define DISPATCH(AY_, NR4_) \
     if (g.Ay == AY_ && nr4 == NR4_) return split_launch_##AY_##_##NR4_(ctx, g, V, R, W, H_inout, neg, pos, fused, reg, s, extra);
     TNMF_SPLIT_SHAPES(DISPATCH)

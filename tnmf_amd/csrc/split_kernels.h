@@ -60,8 +60,13 @@ constexpr int kBlock = 256;
 constexpr int SP_TY = 8, SP_TX = 32, SP_RB = 2;
 
 // compile-time geometry of one (atom rows, runs per row) instantiation
+// AY == 1 is the 1-D instantiation (signals: one row per sample).  There the ROWS of a tile are eight consecutive SAMPLES
+// (no vertical halo), the atom is one row of up to 4 NR4 taps, and the two lane halves of a k block take the two halves
+// of 16 consecutive taps (instead of the two rows of an atom row pair): NR4 is a multiple of 4.
 template <int AY, int NR4>
 struct SplitCfg {
+    static constexpr bool ONE_D = AY == 1;
+    static_assert(!ONE_D || NR4 % 4 == 0, "1-D: whole k blocks of 16 taps");
     static constexpr int WSTR = 4 * NR4 + 28;          // window row stride (bf16 elements): 4 (i >> 2) + b0 + 3 <= WSTR - 1
     static constexpr int Q = WSTR / 4;                 // 4-element pieces per window row
     static constexpr int SH = SP_TY + AY - 1;          // window rows that hold data
@@ -69,7 +74,7 @@ struct SplitCfg {
     static constexpr int raw = SHA * WSTR * 2;
     static constexpr int planeB = ((raw - 64 + 255) / 256) * 256 + 64;   // bytes per (array, copy): == 64 (mod 256)
     static constexpr int NP = (AY + 1) / 2;            // atom row pairs
-    static constexpr int NSLOT = NP * NR4;             // (row pair, run) slots; a k block holds two
+    static constexpr int NSLOT = ONE_D ? NR4 / 2 : NP * NR4;   // (row pair, run) slots -- 1-D: pairs of runs; a k block holds two
     static constexpr int KB = (NSLOT + 1) / 2;
     static constexpr int wimg = KB * 3 * 1024;         // bytes of the W image of one (atom tile, channel)
     static constexpr int win = 24 * planeB;            // 6 arrays x 4 copies
@@ -141,7 +146,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 // W[M][C][Ay][Ax] -> register images Wimg[mt][c][kb][term][lane][8 bf16] of the B operand (see the file header):
 // element j of lane (n = l & 31, h = l >> 5) of k block kb is tap (a = 2p + h, b = 4r + (j & 3)) of slot 2 kb + (j >> 2)
 // = (r, p) with p fastest, zero outside the atom / beyond M.
-__global__ void k_split_prep_W(Geo g, int NP, int NSLOT, int KB, const float *__restrict__ W,
+__global__ void k_split_prep_W(Geo g, int NP, int NSLOT, int KB, int one_d, const float *__restrict__ W,
                                u32x4 *__restrict__ Wimg) {
     const int lane = threadIdx.x;
     const int kb = blockIdx.x % KB;
@@ -153,7 +158,8 @@ __global__ void k_split_prep_W(Geo g, int NP, int NSLOT, int KB, const float *__
     for (int j = 0; j < 8; ++j) {
         const int slot = 2 * kb + (j >> 2);
         const int r = slot / NP, p = slot - r * NP;
-        const int a = 2 * p + h, b = 4 * r + (j & 3);
+        // 1-D: lane half h of k block kb holds taps 16 kb + 8 h + j
+        const int a = one_d ? 0 : 2 * p + h, b = one_d ? 16 * kb + 8 * h + j : 4 * r + (j & 3);
         const bool ok = slot < NSLOT && a < g.Ay && b < g.Ax && m < g.M;
         const float w = ok ? W[(((size_t)m * g.C + c) * g.Ay + a) * g.Ax + b] : 0.f;
         split3(w, t[0][j], t[1][j], t[2][j]);
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
     static_assert(!EXTRA || FUSED, "the extra denominator term belongs to the fused update");
     using Cfg = SplitCfg<AY, NR4>;
     constexpr int WSTR = Cfg::WSTR, Q = Cfg::Q, planeB = Cfg::planeB, KB = Cfg::KB, NSLOT = Cfg::NSLOT, NP = Cfg::NP;
+    constexpr bool ONE_D = Cfg::ONE_D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Wl = smem;                  // [KB][3][64 lanes][16 bytes]
     unsigned char *Xw = smem + Cfg::wimg;      // [6 arrays: V hi, mid, lo, R hi, mid, lo][4 copies][SHA][WSTR] bf16
@@ -241,14 +248,15 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
     // shared lines are read and written within one L2 (the row block of a plane is one contiguous 8.5 KB region);
     // dealt to different workgroups they were fetched twice and written back as partial lines from two XCDs (measured
     // 1.7x the algorithmic H traffic).
-    const int nblocks = g.N * tiles_y;   // row blocks
+    // (1-D: tiles_y = row blocks of eight SAMPLES; n stays 0 and u0 is the first sample of the block)
+    const int nblocks = ONE_D ? tiles_y : g.N * tiles_y;   // row blocks
     auto stage_coords = [&](int st, int &n, int &u0, int &v0, int &c) {
         c = st % g.C;
         const int tl = st / g.C;                                   // tile index within this workgroup's walk
         const int txi = tl % tiles_x;
         const int rbk = blockIdx.x + (tl / tiles_x) * gridDim.x;   // row block
         const int tyi = rbk % tiles_y;
-        n = rbk / tiles_y;
+        n = ONE_D ? 0 : rbk / tiles_y;
         u0 = tyi * SP_TY;
         v0 = txi * SP_TX;
     };
@@ -268,10 +276,16 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
     auto prefetch_setup = [&](int st) {
         int n, u0, v0, c;
         stage_coords(st, n, u0, v0, c);
-        const int y = u0 + wr - (g.Ay - 1);
-        const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1);
-        prow[0] = V + (((size_t)n * g.C + c) * g.Dy + yc) * g.Dx;
-        prow[1] = Rr + (((size_t)n * g.C + c) * g.Dy + yc) * g.Dx;
+        if (ONE_D) {   // window row wr = sample u0 + wr (clamped; rows beyond the last sample are masked in convert)
+            const int sn = u0 + wr < g.N ? u0 + wr : g.N - 1;
+            prow[0] = V + ((size_t)sn * g.C + c) * g.Dx;
+            prow[1] = Rr + ((size_t)sn * g.C + c) * g.Dx;
+        } else {
+            const int y = u0 + wr - (g.Ay - 1);
+            const int yc = y < 0 ? 0 : (y < g.Dy ? y : g.Dy - 1);
+            prow[0] = V + (((size_t)n * g.C + c) * g.Dy + yc) * g.Dx;
+            prow[1] = Rr + (((size_t)n * g.C + c) * g.Dy + yc) * g.Dx;
+        }
         const int x0 = v0 + 4 * wq - (g.Ax - 1);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
         int n, u0, v0, c;
         stage_coords(st, n, u0, v0, c);
         const int y = u0 + wr - (g.Ay - 1);
-        const bool yok = y >= 0 && y < g.Dy;
+        const bool yok = ONE_D ? u0 + wr < g.N : (y >= 0 && y < g.Dy);
         const int x0 = v0 + 4 * wq - (g.Ax - 1);
         float fv[7], fr[7];
         // wave-uniform: every 4-column piece of this tile's window lies inside the image row (the second piece of the
@@ -358,7 +372,9 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
     // permutation the epilogue's two register<->lane bit exchanges (see there) leave every lane with FOUR CONSECUTIVE
     // pixels of one atom and eight adjacent lanes with 128 contiguous bytes.  Copy pj & 3 = j >> 3, element 4 (pj >> 2):
     // the 32 lanes of a half wave still cover the 64 banks exactly once.
-    const unsigned char *abase = Xw + (j >> 3) * planeB + ((2 * wave + h) * WSTR + 4 * (j & 7)) * 2;
+    // (1-D: lane half h is 8 taps further along the row, not one row further down)
+    const unsigned char *abase = Xw + (j >> 3) * planeB +
+                                 (ONE_D ? (2 * wave) * WSTR + 4 * (j & 7) + 8 * h : (2 * wave + h) * WSTR + 4 * (j & 7)) * 2;
     const unsigned char *bbase = Wl + lane * 16;
 
     f32x16 acc[SP_RB][2];   // [row of the wave][V | R]
@@ -405,25 +421,33 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
         // the pad columns are part of the last tile -- they are read, updated and written like pixels, 0 stays 0, nobody
         // else looks at them); the separate neg / pos outputs of the unfused call are C-contiguous.
         const int hs = FUSED ? g.Hs : g.Hx;
-        const unsigned plane4 = (unsigned)g.Hy * hs * 4;     // bytes of one atom plane
+        const unsigned plane4 = (unsigned)g.Hy * hs * 4;     // bytes of one atom plane (1-D: of one atom's row)
         const int p0 = v0 + 4 * (j & 7);                     // first of this lane's four pixels
         const int p0c = p0 < hs - 4 ? p0 : hs - 4;
         const bool interior = v0 + SP_TX <= hs;              // wave-uniform: whole tile inside the (padded) row
-        const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(Hio + (size_t)n * g.M * g.Hy * hs), 0, (int)(g.M * plane4), 0x00020000);
+        // 2-D: one descriptor per sample (M planes); a row is an offset inside it.  1-D: the rows of the tile are samples, so
+        // the descriptor covers the M rows of ONE sample and each of the wave's two rows gets its own (rsrc_of below): the
+        // range check drops the atoms beyond M either way.
+        const int nrows = ONE_D ? g.N : g.Hy;
+        auto rsrc_of = [&](const float *base, int rb) {
+            const int u = u0 + wave * SP_RB + rb;
+            const size_t first = ONE_D ? (size_t)(u < nrows ? u : nrows - 1) * g.M * hs : (size_t)n * g.M * g.Hy * hs;
+            return __builtin_amdgcn_make_buffer_rsrc((void *)(base + first), 0, (int)(g.M * plane4), 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t hrsrc2[SP_RB] = {rsrc_of(Hio, 0), rsrc_of(Hio, 1)};
         unsigned hoff[SP_RB];   // byte offset of (atom of register group 0, row, first pixel), start column clamped
 #pragma unroll
         for (int rb = 0; rb < SP_RB; ++rb) {
             const int u = u0 + wave * SP_RB + rb;
             hoff[rb] = (unsigned)(mt * 32 + ((j >> 3) & 3) + 4 * h) * plane4 +
-                       ((unsigned)(u < g.Hy ? u : g.Hy - 1) * hs + p0c) * 4;
+                       ((ONE_D ? 0u : (unsigned)(u < g.Hy ? u : g.Hy - 1) * hs) + p0c) * 4;
         }
         // H values of this lane's outputs, consumed only in the epilogue: UNCONDITIONAL 16-byte loads on clamped, always
         // legal addresses, issued one per MFMA group from inside the loop (mem_slot)
         const bool hload = FUSED && LAST && !(TNMF_ABL(ablate) & 128);
         auto h_issue = [&](int k) {   // k = 0..7 = (row of the wave, register group)
             const int rb = k >> 2, q = k & 3;
-            const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (int)(hoff[rb] + 8u * q * plane4), 0, 0);
+            const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(hrsrc2[rb], (int)(hoff[rb] + 8u * q * plane4), 0, 0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned w = t4[e];
@@ -457,7 +481,8 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
                     int slot = 2 * kb + e;
                     if (slot >= NSLOT) slot = NSLOT - 1;   // odd slot count: W is zero there, any legal address serves
                     const int r = slot / NP, p = slot - r * NP;   // consecutive slots: consecutive row pairs, same run
-                    const int off = ((rb + 2 * p) * WSTR + 4 * r) * 2;
+                    // (1-D: slot = run pair: taps 16 kb + 4 e + 8 h, the 8 h sits in the lane base)
+                    const int off = ONE_D ? (rb * WSTR + 16 * kb + 4 * e) * 2 : ((rb + 2 * p) * WSTR + 4 * r) * 2;
 #pragma unroll
                     for (int term = 0; term < 3; ++term)
                         a[buf][term][e] = *reinterpret_cast<const u32x2 *>(abase + (3 * x + term) * 4 * planeB + off);
@@ -504,11 +529,19 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
                 // instantiation; two plain scheduling fences per group give the same instruction stream.)
                 __builtin_amdgcn_sched_barrier(0);
             });
+            // short loops (the 1-D instantiations with few taps: fewer than 12 groups): the memory slots the loop had no
+            // group for are issued behind it
+            static_for<12>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int MSTRIDE = G >= 24 ? G / 24 : 1;
+                if constexpr (k >= (G + MSTRIDE - 1) / MSTRIDE) mem_slot(k);
+            });
         }
 
         SP_STAMP(4);     // MFMA loop
         float ev[SP_RB][16];
         if constexpr (EXTRA && LAST) {
+            static_assert(!EXTRA || !ONE_D, "the extra-term epilogue is instantiated for 2-D problems only");
             const __amdgpu_buffer_rsrc_t ersrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(Ex + (size_t)n * g.M * g.Hy * hs), 0, (int)(g.M * plane4), 0x00020000);
 #pragma unroll
@@ -577,15 +610,13 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
             // The arithmetic consumes every prefetched H value UNCONDITIONALLY (only the stores are predicated): a load
             // whose result is used on some paths only stays "pending" for hipcc's wait-count pass at the loop back edge,
             // and the next stage's H loads into the same registers would then wait for the window prefetch in between.
-            const size_t sample = (size_t)n * g.M * g.Hy * hs;
-            const __amdgpu_buffer_rsrc_t nrsrc =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(neg + (FUSED ? 0 : sample)), 0, (int)(g.M * plane4), 0x00020000);
-            const __amdgpu_buffer_rsrc_t prsrc =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(pos + (FUSED ? 0 : sample)), 0, (int)(g.M * plane4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t nrsrc2[SP_RB] = {rsrc_of(FUSED ? Hio : neg, 0), rsrc_of(FUSED ? Hio : neg, 1)};
+            const __amdgpu_buffer_rsrc_t prsrc2[SP_RB] = {rsrc_of(FUSED ? Hio : pos, 0), rsrc_of(FUSED ? Hio : pos, 1)};
 #pragma unroll
             for (int rb = 0; rb < SP_RB; ++rb) {
                 const int u = u0 + wave * SP_RB + rb;
-                const bool urow = u < g.Hy;
+                const bool urow = u < nrows;
+                const __amdgpu_buffer_rsrc_t hrsrc = hrsrc2[rb], nrsrc = nrsrc2[rb], prsrc = prsrc2[rb];
                 // un-clamped offset of the first pixel (the stores of a border tile go element by element)
                 const unsigned soff = hoff[rb] + (unsigned)(p0 - p0c) * 4;
 #pragma unroll
@@ -652,7 +683,7 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
            float *neg, float *pos, bool fused, float reg, hipStream_t s, const float *extra) {
     using Cfg = SplitCfg<AY, NR4>;
     // the extra-term epilogue loads whole 16-byte groups at H's own offsets: row-padded activations only
-    if (extra && (!fused || g.Hs % SP_TX != 0)) return TNMF_E_UNSUPPORTED;
+    if (extra && (!fused || g.Hs % SP_TX != 0 || Cfg::ONE_D)) return TNMF_E_UNSUPPORTED;
     const int MT = cdiv(g.M, 32);
     const size_t wbytes = (size_t)MT * g.C * Cfg::wimg;
     if (wbytes > ctx->wimg_bytes) {
@@ -668,15 +699,17 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
         }
         ctx->wimg_bytes = wbytes;
     }
-    hipLaunchKernelGGL(k_split_prep_W, dim3(MT * g.C * Cfg::KB), dim3(64), 0, s, g, Cfg::NP, Cfg::NSLOT, Cfg::KB, W,
-                       (u32x4 *)ctx->wimg);
-    const int tiles_y = cdiv(g.Hy, SP_TY), tiles_x = cdiv(g.Hx, SP_TX);
-    const long ntiles = (long)g.N * tiles_y * tiles_x;
+    hipLaunchKernelGGL(k_split_prep_W, dim3(MT * g.C * Cfg::KB), dim3(64), 0, s, g, Cfg::NP, Cfg::NSLOT, Cfg::KB,
+                       Cfg::ONE_D ? 1 : 0, W, (u32x4 *)ctx->wimg);
+    // (1-D: the rows of a tile are samples: row blocks of eight samples, one "plane")
+    const int tiles_y = Cfg::ONE_D ? cdiv(g.N, SP_TY) : cdiv(g.Hy, SP_TY), tiles_x = cdiv(g.Hx, SP_TX);
+    const long nrowblocks = Cfg::ONE_D ? tiles_y : (long)g.N * tiles_y;
+    const long ntiles = nrowblocks * tiles_x;
     if (ntiles > 0x7fffffffL) return TNMF_E_GEOM;
     const int per_cu = Cfg::lds <= 80 * 1024 ? 2 : 1;
     long P = ((long)per_cu * ctx->num_cu) / MT;
     if (P < 1) P = 1;
-    if (P > (long)g.N * tiles_y) P = (long)g.N * tiles_y;   // a workgroup walks whole row blocks
+    if (P > nrowblocks) P = nrowblocks;   // a workgroup walks whole row blocks
     const dim3 grid((unsigned)P, MT);
     unsigned long long *dbg = nullptr;
     const size_t nw = (size_t)P * MT * 4;
@@ -686,10 +719,12 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
     hipLaunchKernelGGL((k_split_corr_W<FUSED_, MULTI_, AY, NR4, EXTRA_>), grid, dim3(kBlock), Cfg::lds, s, g, tiles_y,   \
                        tiles_x, ctx->ablate, dbg, V, R, (const u32x4 *)ctx->wimg, H_, NEG_, POS_, REG_, extra)
     if (fused && extra) {
-        if (g.C > 1)
-            SPLIT_LAUNCH(true, true, true, H_inout, (float *)nullptr, (float *)nullptr, reg);
-        else
-            SPLIT_LAUNCH(true, false, true, H_inout, (float *)nullptr, (float *)nullptr, reg);
+        if constexpr (!Cfg::ONE_D) {
+            if (g.C > 1)
+                SPLIT_LAUNCH(true, true, true, H_inout, (float *)nullptr, (float *)nullptr, reg);
+            else
+                SPLIT_LAUNCH(true, false, true, H_inout, (float *)nullptr, (float *)nullptr, reg);
+        }
     } else if (fused) {
         if (g.C > 1)
             SPLIT_LAUNCH(true, true, false, H_inout, (float *)nullptr, (float *)nullptr, reg);
@@ -732,8 +767,10 @@ int prepare_one() {
     SPLIT_ATTR(true, false, false);
     SPLIT_ATTR(false, true, false);
     SPLIT_ATTR(false, false, false);
-    SPLIT_ATTR(true, true, true);
-    SPLIT_ATTR(true, false, true);
+    if constexpr (!SplitCfg<AY, NR4>::ONE_D) {
+        SPLIT_ATTR(true, true, true);
+        SPLIT_ATTR(true, false, true);
+    }
 #undef SPLIT_ATTR
     return TNMF_OK;
 }
