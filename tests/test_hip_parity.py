@@ -288,6 +288,13 @@ SPLIT_SHAPES = [
     (2, 3, (50, 50), 10, (7, 7)),
     (1, 1, (9, 300), 3, (8, 5)),
     (2, 1, (40, 8), 64, (5, 8)),
+    # atom shapes between the instantiations: they run on the smallest covering one (zero rows / taps in the operand image)
+    (2, 1, (50, 60), 20, (10, 10)),
+    (1, 2, (40, 44), 8, (6, 6)),
+    (2, 1, (33, 70), 33, (13, 14)),
+    (1, 1, (30, 30), 4, (11, 5)),
+    (1, 1, (25, 40), 6, (3, 16)),
+    (2, 1, (20, 20), 5, (3, 3)),
 ]
 
 

@@ -124,7 +124,7 @@ bool use_split(const tnmf_hip_ctx *ctx, const Geo &g, int dtype) {
     // (tiny calls -- the batches of the stochastic schedules -- are launch latency: the split kernel needs an operand
     // preparation launch in front of it, the generic kernel does not)
     if (ctx->path == TNMF_PATH_AUTO && (size_t)g.N * g.M * g.Hy * g.Hx < ((size_t)1 << 16)) return false;
-    return ctx->split && split_has_corr_W(g, dtype);
+    return ctx->split && split_has_corr_W(g, dtype, true);
 }
 
 bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {

@@ -4,7 +4,9 @@
 #include "common.h"
 
 // shape support: float32, 2-D, atoms up to 16 x 16 (the specialised instantiations are listed in split.hip)
-bool split_has_corr_W(const Geo &g, int dtype);
+// (every atom up to 16 x 16 runs on the smallest covering instantiation; only_if_worth: not when the zero padding of that
+// instantiation costs more than the exact f32 kernels would)
+bool split_has_corr_W(const Geo &g, int dtype, bool only_if_worth = false);
 // neg/pos of the H gradient (fused == false) or H = H * neg / (pos + reg) in place (fused == true); R is given
 // extra (fused, row-padded H only; may be NULL): a further term of the denominator, laid out like H
 int split_corr_W(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, const float *W, float *H_inout,
