@@ -1,14 +1,37 @@
 #!/bin/bash
 # Round-end measurement batch on the GPU box: bench lines, rocprof kernel stats and FETCH/WRITE PMC passes of every
-# BASELINE configuration that fits one GPU (2, 3, 4-shard, 5-shard), Cyclic-MU lines of configs 4 and 5.
-# usage (through gpurun): bash tools/final_measure.sh <tag> [configs, default "3 2 4 5"]   -> gpurun_out/final_<tag>/
+# BASELINE configuration that fits one GPU (2, 3, 4-shard, 5-shard), Cyclic-MU lines of configs 4 and 5, the small-batch
+# schedules, the inhibition leg.
+# usage (through gpurun): bash tools/final_measure.sh <tag> [configs, default "3 2 4 5"] [nobench]  -> gpurun_out/final_<tag>/
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=${1:-r}
 configs=${2:-"3 2 4 5"}
 out=$R/gpurun_out/final_$tag
 mkdir -p $out
+cd $R
+Q="--no-cpu-baseline --no-fft-variant --no-parity"
+if [ "$3" != "nobench" ]; then
+  timeout -k 10 500 python3 bench.py > $out/bench_n1.json 2> $out/bench_n1.err || { echo "bench failed"; tail -3 $out/bench_n1.err; exit 1; }
+  echo "bench n1 done"
+  for c in 2 4 5; do
+    timeout -k 10 400 python3 bench.py --config $c --no-cpu-baseline --steps 8 --warmup 2 > $out/bench_config$c.json 2> $out/bench_config$c.err || { echo "bench $c failed"; exit 1; }
+    echo "bench config $c done"
+  done
+  timeout -k 10 300 python3 bench.py --config 4 $Q --steps 8 --warmup 2 --algorithm cyclic --batch-size 64 > $out/bench_config4_cyclic.json 2> $out/b.err || exit 1
+  timeout -k 10 300 python3 bench.py --config 5 $Q --steps 8 --warmup 2 --algorithm cyclic --batch-size 32 > $out/bench_config5_cyclic.json 2> $out/b.err || exit 1
+  timeout -k 10 300 python3 bench.py $Q --steps 10 --warmup 2 --inhibition 0.1 > $out/bench_config3_inhibition.json 2> $out/b.err || exit 1
+  timeout -k 10 300 python3 bench.py $Q --steps 10 --warmup 2 --inhibition 0.1 --cross-inhibition 0.05 > $out/bench_config3_inhibition_cross.json 2> $out/b.err || exit 1
+  timeout -k 10 300 python3 bench.py --config 1 $Q --steps 200 --warmup 20 > $out/bench_config1.json 2> $out/b.err || exit 1
+  timeout -k 10 300 python3 bench.py --config 1 $Q --steps 200 --warmup 20 --eager > $out/bench_config1_eager.json 2> $out/b.err || exit 1
+  timeout -k 10 300 python3 bench.py --config 7 $Q --steps 20 --warmup 3 > $out/bench_long_1d.json 2> $out/b.err || exit 1
+  for a in asg asag cyclic gsg gsag; do
+    timeout -k 10 300 python3 bench.py --config 8 --batch-size 3 $Q --steps 5 --warmup 2 --algorithm $a > $out/bench_minibatch_geometry_$a.json 2> $out/b.err || exit 1
+    timeout -k 10 300 python3 bench.py --config 8 --batch-size 3 $Q --steps 5 --warmup 2 --algorithm $a --eager > $out/bench_minibatch_geometry_${a}_eager.json 2> $out/b.err || exit 1
+  done
+  echo "bench legs done"
+fi
 cd /tmp && export TMPDIR=/tmp
-PROF_ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-fft-variant --no-parity"
+PROF_ARGS="--steps 10 --warmup 2 $Q"
 for c in $configs; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_config$c -o s -- python3 $R/bench.py --config $c $PROF_ARGS > $out/stats_config$c.log 2>&1 || { echo "stats $c failed"; tail -3 $out/stats_config$c.log; exit 1; }
   echo "stats config $c done"
