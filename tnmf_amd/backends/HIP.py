@@ -544,7 +544,10 @@ class HIP_Backend(Backend):
             kp = [kk.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for kk in ks] + [None, None]
             kl = [len(kk) for kk in ks] + [0, 0]
             Rs = self._R_scratch[ls]
-            self._foreign_H()     # (what the cache holds about these samples is about to be stale)
+            if self._mode == 0:
+                self._validate_H_cache(Hs, W)   # (the library drops the spectra of the samples it updates itself)
+            else:
+                self._foreign_H()
 
             def run_ex(Hc, ld):
                 with self._timed('update_H'):
@@ -558,9 +561,11 @@ class HIP_Backend(Backend):
                 assert Hs.is_contiguous()
                 rc, where = run_ex(Hs, 0)
                 _lib.check(rc, where)
+                self._foreign_H()
+            elif self._call_H(Hs, True, run_ex):
+                self._foreign_H()   # the library updated (and kept spectra of) a temporary copy
             else:
-                self._call_H(Hs, True, run_ex)
-            self._foreign_H()
+                self._note_H_cache(Hs, W)
             return
         Rs = self._R_scratch[ls]
         self._validate_H_cache(Hs, W)
