@@ -58,21 +58,102 @@ __device__ __forceinline__ void reconstruct_block(const Geo &g, const Tile &t, u
     const int ty = threadIdx.x / t.TX, tx = threadIdx.x % t.TX;
 
     T acc = T(0);
-    for (int m = 0; m < g.M; ++m) {
-        const T *h = H + ((size_t)n * g.M + m) * g.Hy * g.Hs;   // (rows of H may be padded: g.Hs >= g.Hx)
-        const T *w = W + ((size_t)m * g.C + c) * nA;
-        __syncthreads();
-        for (int i = threadIdx.x; i < SH * SW; i += kBlock) {
-            const int r = i / SW, q = i - r * SW;
-            const int hy = y0 + r, hx = x0 + q;
-            Hs[i] = (hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hs + hx] : T(0);
+    // Staging through registers: the H tile (+ halo) and the flipped atom of the atoms AHEAD are fetched -- all loads of an
+    // atom in flight at once, row and column of element tid + 256 k by constant increments -- while the current atom is
+    // multiplied, and parked in LDS behind it.  (One load per loop iteration, each waited for, made small calls a chain of
+    // memory latencies: 37 us for 3 samples of 32 x 32 with ten atoms -- the batches of the stochastic schedules.)
+    //   small tiles (<= 3 values per thread, atoms <= 256 taps): kDeep = 4 atoms in flight (ring of register slots,
+    //   the atom loop unrolled by four so that every slot index is static);
+    //   larger tiles (<= kPre values per thread): one atom ahead;  beyond that: the plain loop.
+    constexpr int kPre = 12, kDeep = 4, kPer = kPre / kDeep, kWPre = 4;
+    const int nel = SH * SW;
+    const int dr = kBlock / SW, dq = kBlock - dr * SW;
+    const int r_first = (int)threadIdx.x / SW, q_first = (int)threadIdx.x - r_first * SW;
+    const bool deep = nel <= kPer * kBlock && nA <= kBlock;
+    const bool pre_ok = nel <= kPre * kBlock, wpre_ok = nA <= kWPre * kBlock;
+    T pre[kPre], wpre[kWPre];
+    // fetch atom m_ into pre[p0 .. p0 + cnt) and wpre[w0 .. w0 + wcnt)
+    auto fetch = [&](int m_, int p0, int cnt, int w0, int wcnt) {
+        const T *h = H + ((size_t)n * g.M + m_) * g.Hy * g.Hs;   // (rows of H may be padded: g.Hs >= g.Hx)
+        const T *w_ = W + ((size_t)m_ * g.C + c) * nA;
+#pragma unroll
+        for (int k = 0; k < kWPre; ++k) {
+            const int i = k * kBlock + threadIdx.x;
+            if (k < wcnt) wpre[w0 + k] = i < nA ? w_[nA - 1 - i] : T(0);
         }
-        for (int i = threadIdx.x; i < nA; i += kBlock) Ws[i] = w[nA - 1 - i];  // flipped atom
-        __syncthreads();
+        int r = r_first, q = q_first;
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+            if (k < cnt) {
+                const int hy = y0 + r, hx = x0 + q;
+                pre[p0 + k] =
+                    (k * kBlock + (int)threadIdx.x < nel && hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hs + hx] : T(0);
+                r += dr;
+                q += dq;
+                if (q >= SW) {
+                    q -= SW;
+                    ++r;
+                }
+            }
+        }
+    };
+    auto park = [&](int p0, int cnt, int w0, int wcnt) {
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+            const int i = k * kBlock + threadIdx.x;
+            if (k < cnt && i < nel) Hs[i] = pre[p0 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < kWPre; ++k) {
+            const int i = k * kBlock + threadIdx.x;
+            if (k < wcnt && i < nA) Ws[i] = wpre[w0 + k];   // flipped atom (fetched with the tile)
+        }
+    };
+    auto multiply = [&]() {
         for (int a = 0; a < g.Ay; ++a) {
             const T *hr = Hs + (ty + a) * SW + tx;
             const T *wr = Ws + a * g.Ax;
+            // (unrolled: eight LDS reads in flight instead of one -- the additions keep their order)
+#pragma unroll 8
             for (int b = 0; b < g.Ax; ++b) acc += hr[b] * wr[b];
+        }
+    };
+    if (deep) {
+#pragma unroll
+        for (int d = 0; d < kDeep; ++d)
+            if (d < g.M) fetch(d, d * kPer, kPer, d, 1);
+        for (int m0 = 0; m0 < g.M; m0 += kDeep) {
+#pragma unroll
+            for (int d = 0; d < kDeep; ++d) {
+                const int m = m0 + d;
+                if (m < g.M) {   // (uniform)
+                    __syncthreads();
+                    park(d * kPer, kPer, d, 1);
+                    __syncthreads();
+                    if (m + kDeep < g.M) fetch(m + kDeep, d * kPer, kPer, d, 1);   // in flight under the next atoms
+                    multiply();
+                }
+            }
+        }
+    } else {
+        if (pre_ok && wpre_ok) fetch(0, 0, kPre, 0, kWPre);
+        for (int m = 0; m < g.M; ++m) {
+            const T *h = H + ((size_t)n * g.M + m) * g.Hy * g.Hs;
+            const T *w = W + ((size_t)m * g.C + c) * nA;
+            __syncthreads();
+            if (pre_ok && wpre_ok) {
+                park(0, kPre, 0, kWPre);
+            } else {
+                for (int i = threadIdx.x; i < nel; i += kBlock) {
+                    const int r = i / SW, q = i - r * SW;
+                    const int hy = y0 + r, hx = x0 + q;
+                    Hs[i] = (hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hs + hx] : T(0);
+                }
+                for (int i = threadIdx.x; i < nA; i += kBlock) Ws[i] = w[nA - 1 - i];  // flipped atom
+            }
+            __syncthreads();
+            if (pre_ok && wpre_ok && m + 1 < g.M) fetch(m + 1, 0, kPre, 0, kWPre);   // in flight under the multiply-adds
+            multiply();
         }
     }
     const int y = y0 + ty, x = x0 + tx;
@@ -131,6 +212,7 @@ __device__ __forceinline__ void corr_W_block(const Geo &g, const Tile &t, unsign
             const T *vr = Vs + (ty + a) * SW + tx;
             const T *rr = Rs + (ty + a) * SW + tx;
             const T *wr = Ws + a * g.Ax;
+#pragma unroll 8
             for (int b = 0; b < g.Ax; ++b) {
                 an += wr[b] * vr[b];
                 ap += wr[b] * rr[b];
@@ -223,6 +305,7 @@ __device__ __forceinline__ void corr_H_block(const Geo &g, const Tile &t, int P,
                 if (s < nA) {
                     const int a = s / g.Ax, b = s - a * g.Ax;
                     T pn = T(0), pp = T(0);
+#pragma unroll 4
                     for (int pix = grp; pix < npix; pix += G) {
                         const int y = pix / t.TX, x = pix - y * t.TX;
                         const T hv = Hs[(y + a) * SW + x + b];
