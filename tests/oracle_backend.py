@@ -12,7 +12,7 @@ from tnmf_amd.backends._Backend import Backend, sliceNone
 
 
 class OracleBackend(Backend):
-    def __init__(self, reconstruction_mode='valid', impl='c', process_group=None, hooks=False):
+    def __init__(self, reconstruction_mode='valid', impl='c', process_group=None, hooks=False, schedules=False):
         if reconstruction_mode != 'valid':
             raise NotImplementedError
         super().__init__(reconstruction_mode)
@@ -31,6 +31,12 @@ class OracleBackend(Backend):
             self.fused_update_W = self._fused_update_W
             self.fused_update_H = self._fused_update_H
             self.minibatch_slices = self._minibatch_slices
+        self.schedule_calls = []
+        if hooks and schedules:   # ... and the operation-list hook (HIP_Backend.run_schedule), interpreted with the oracle
+            self.supports_schedules = process_group is None
+            self.run_schedule = self._run_schedule
+            self.prefers_schedule = lambda H: True
+            self.new_gradient_accumulator = lambda W: np.empty((2,) + W.shape, dtype=W.dtype)
 
     # -- set-up: same helpers as HIP_Backend._initialize_matrices --
     def _initialize_matrices(self, V, atom_shape, n_atoms, W=None, axes_W_normalization=None):
@@ -95,6 +101,21 @@ class OracleBackend(Backend):
 
     def _fused_update_W(self, V, W, H, s=sliceNone, eps=1e-9):
         self._apply_W(W, self._reduce(self._local_gradient_W(V, W, H, s)), eps)
+
+    def _run_schedule(self, V, W, H, ops, acc, sparsity=0., eps=1e-9):
+        """The contract of tnmf_hip_run_schedule (include/tnmf_hip.h), step by step with the oracle's primitives."""
+        self.schedule_calls.append([op[0] for op in ops])
+        for op in ops:
+            if op[0] == 'H':
+                self._fused_update_H(V, W, H, op[1], sparsity=sparsity, eps=eps)
+            elif op[0] == 'G':
+                g = self._local_gradient_W(V, W, H, op[1])
+                a, b = op[2], op[3]
+                acc[...] = b * g if a == 0 else a * acc + b * g
+            elif op[0] == 'W':
+                self._apply_W(W, acc, eps)            # (leaves acc[1] incremented by eps, like the reference's :232)
+            else:
+                raise ValueError(op)
 
     def _fused_update_H(self, V, W, H, s=sliceNone, sparsity=0., eps=1e-9, inhibition=0., cross_inhibition=0.,
                         inhibition_kernels=None):

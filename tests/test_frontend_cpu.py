@@ -71,3 +71,45 @@ def test_progress_callback_stops():
 def test_unknown_backend_name():
     with pytest.raises(KeyError):
         TransformInvariantNMF(n_atoms=2, atom_shape=(3,), backend='numpy_fft')
+
+
+@pytest.mark.parametrize('algorithm', list(MiniBatchAlgorithm))
+def test_epochs_as_operation_lists_equal_the_batch_by_batch_schedules(algorithm):
+    """The front end describes a mini-batch epoch as ONE operation list for backends that offer `run_schedule`
+    (HIP_Backend -> tnmf_hip_run_schedule): H half steps, gradient blends acc = a * acc + b * g with the coefficients of
+    reference TransformInvariantNMF.py:444-455 (first use from the integer 0 included), W updates.  Interpreted step by step
+    with the oracle's primitives, the lists must reproduce the batch-by-batch schedules -- same RNG draws, same accumulator
+    side effect (pos += eps) across epochs."""
+    rng = np.random.default_rng(3)
+    V = rng.random((7, 2, 12, 14))
+    kw = dict(algorithm=algorithm, batch_size=2, n_epochs=3, sag_lambda=0.8, sparsity_H=0.05)
+    res = {}
+    for flavour in ('lists', 'batch_by_batch'):
+        np.random.seed(42)
+        be = OracleBackend(hooks=True, schedules=flavour == 'lists')
+        nmf = TransformInvariantNMF(n_atoms=3, atom_shape=(3, 4), backend=be)
+        nmf.fit(V, **kw)
+        res[flavour] = (nmf.W, nmf.H)
+        if flavour == 'lists':
+            assert len(be.schedule_calls) == 3, 'one operation list per epoch'
+            per_batch = {'Cyclic_MU': ['H', 'G'], 'ASG_MU': ['H', 'G', 'W'], 'ASAG_MU': ['H', 'G', 'W']}.get(algorithm.name)
+            if per_batch:
+                assert be.schedule_calls[0][:len(per_batch)] == per_batch
+            else:   # GSG / GSAG: H for every batch, then one gradient and one W update
+                assert be.schedule_calls[0] == ['H'] * 4 + ['G', 'W']
+    np.testing.assert_allclose(res['lists'][0], res['batch_by_batch'][0], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(res['lists'][1], res['batch_by_batch'][1], rtol=1e-12, atol=1e-300)
+
+
+def test_tiny_full_batch_iterations_go_out_as_operation_lists():
+    """fit_batch of a problem the backend calls tiny: one ('H', all), ('G', all, 0, 1), ('W',) list per iteration."""
+    np.random.seed(42)
+    be = OracleBackend(hooks=True, schedules=True)
+    nmf = TransformInvariantNMF(n_atoms=3, atom_shape=(5,), backend=be)
+    nmf.fit(V_1D, n_iterations=4, sparsity_H=0.1)
+    assert be.schedule_calls == [['H', 'G', 'W']] * 4
+    np.random.seed(42)
+    ref = _nmf(n_atoms=3, atom_shape=(5,))
+    ref.fit(V_1D, n_iterations=4, sparsity_H=0.1)
+    np.testing.assert_allclose(nmf.W, ref.W, rtol=1e-12)
+    np.testing.assert_allclose(nmf.H, ref.H, rtol=1e-12)
