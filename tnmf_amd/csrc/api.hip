@@ -2,6 +2,7 @@
 // dispatch between the kernel families.  No torch types, no exceptions, no allocation inside a call once
 // tnmf_hip_ctx_reserve() has sized the scratch.
 #include <cstdlib>
+#include <cstring>
 #include <new>
 
 #include "fft.h"
@@ -315,6 +316,10 @@ int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx) {
     fft_release(ctx);
     split_release(ctx);
     if (ctx->hw) (void)hipFree(ctx->hw);
+    for (int i = 0; i < tnmf_hip_ctx::kOpSlots; ++i) {
+        if (ctx->ops_done[i]) (void)hipEventDestroy(ctx->ops_done[i]);
+        if (ctx->ops_pinned[i]) (void)hipHostFree(ctx->ops_pinned[i]);
+    }
     if (ctx->ws) {
         const hipError_t e = hipFree(ctx->ws);
         if (e != hipSuccess) rc = (int)e;
@@ -642,7 +647,26 @@ int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
         double *partials = reinterpret_cast<double *>(ws_at(ctx, r_bytes));
         tnmf_hip_op *ops_dev = reinterpret_cast<tnmf_hip_op *>(ws_at(ctx, r_bytes + p_bytes));
         unsigned *counter = reinterpret_cast<unsigned *>(ws_at(ctx, r_bytes + p_bytes + o_bytes));
-        TNMF_HIP_TRY(hipMemcpyAsync(ops_dev, ops, (size_t)n_ops * sizeof(tnmf_hip_op), hipMemcpyHostToDevice, s));
+        {
+            const int slot = ctx->ops_next;
+            ctx->ops_next = (slot + 1) % tnmf_hip_ctx::kOpSlots;
+            const size_t need = (size_t)n_ops * sizeof(tnmf_hip_op);
+            if (ctx->ops_done[slot]) TNMF_HIP_TRY(hipEventSynchronize(ctx->ops_done[slot]));   // (4 calls ago: long done)
+            else TNMF_HIP_TRY(hipEventCreateWithFlags(&ctx->ops_done[slot], hipEventDisableTiming));
+            if (ctx->ops_cap[slot] < need) {
+                if (ctx->ops_pinned[slot]) TNMF_HIP_TRY(hipHostFree(ctx->ops_pinned[slot]));
+                ctx->ops_pinned[slot] = nullptr;
+                ctx->ops_cap[slot] = 0;
+                if (hipHostMalloc(&ctx->ops_pinned[slot], align_up(need, 4096), hipHostMallocDefault) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return TNMF_E_WORKSPACE;
+                }
+                ctx->ops_cap[slot] = align_up(need, 4096);
+            }
+            memcpy(ctx->ops_pinned[slot], ops, need);
+            TNMF_HIP_TRY(hipMemcpyAsync(ops_dev, ctx->ops_pinned[slot], need, hipMemcpyHostToDevice, s));
+            TNMF_HIP_TRY(hipEventRecord(ctx->ops_done[slot], s));
+        }
         fft_invalidate(ctx);   // H and W change under the family's caches
         ctx->last_path = "generic";
         return generic_run_schedule(ctx, g, dtype, V, W_inout, H_inout, Rs, acc, partials, P, ops_dev, n_ops, reg, eps,

@@ -66,6 +66,14 @@ struct tnmf_hip_ctx {
     size_t wimg_bytes;
     void *hw = nullptr;     // activation-sized work arrays of tnmf_hip_update_H_ex (lateral terms, padded H, its gradients)
     size_t hw_bytes = 0;
+    // persistent schedule kernel: the operation list travels host -> device through a ring of PINNED staging slots (an
+    // asynchronous copy from the caller's pageable array could still be reading it after the call has returned); a slot is
+    // reused only after the copy that read it has completed (one event per slot)
+    static constexpr int kOpSlots = 4;
+    void *ops_pinned[kOpSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ops_cap[kOpSlots] = {0, 0, 0, 0};
+    hipEvent_t ops_done[kOpSlots] = {nullptr, nullptr, nullptr, nullptr};
+    int ops_next = 0;
     FftState fft;
 };
 
