@@ -167,6 +167,91 @@ __global__ __launch_bounds__(kBlock) void k_reconstruct(Geo g, Tile t, const T *
     reconstruct_block<T>(g, t, blockIdx.x, W, H, R, smem_raw);
 }
 
+// reconstruct for SMALL calls (the batches of the stochastic schedules: three samples of 32 x 32): the kernel above would
+// run a dozen workgroups, each walking all atoms one after the other -- 26 us of a chip that is otherwise idle.  Here a
+// workgroup owns 2 rows x 32 columns of one (sample, channel) and its four waves take the atoms m = q, q + 4, ... each with
+// an LDS tile of its own; their partial sums are added in wave order (fixed) at the end: four times the workgroups, a
+// quarter of the serial chain.  Rows of H may be padded (g.Hs).
+constexpr int kSmallTY = 2, kSmallTX = 32, kSmallQ = 4;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reconstruct_small(Geo g, int tiles_y, int tiles_x, const T *__restrict__ W,
+                                                              const T *__restrict__ H, T *__restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int SH = kSmallTY + g.Ay - 1, SW = kSmallTX + g.Ax - 1, nel = SH * SW, nA = g.Ay * g.Ax;
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    T *Hs = reinterpret_cast<T *>(smem_raw) + (size_t)q * (nel + nA);
+    T *Ws = Hs + nel;
+    T *red = reinterpret_cast<T *>(smem_raw) + (size_t)kSmallQ * (nel + nA);   // [kSmallQ][64]
+    unsigned bid = blockIdx.x;
+    const int txi = bid % tiles_x;
+    bid /= tiles_x;
+    const int tyi = bid % tiles_y;
+    bid /= tiles_y;
+    const int c = bid % g.C, n = bid / g.C;
+    const int y0 = tyi * kSmallTY, x0 = txi * kSmallTX;
+    const int ty = lane / kSmallTX, tx = lane % kSmallTX;
+    constexpr int kPre = 12;   // tile elements per lane in the register stage (64 lanes per tile); beyond: plain loop
+    const bool pre_ok = nel <= kPre * 64 && nA <= 4 * 64;
+    T acc = T(0);
+    for (int m0 = 0; m0 < g.M; m0 += kSmallQ) {
+        const int m = m0 + q;
+        const bool has = m < g.M;   // (wave-uniform)
+        const T *h = H + ((size_t)n * g.M + (has ? m : 0)) * g.Hy * g.Hs;
+        const T *w = W + ((size_t)(has ? m : 0) * g.C + c) * nA;
+        __syncthreads();   // every wave is done with its previous tile
+        if (has) {
+            if (pre_ok) {
+                T pre[kPre], wpre[4];
+#pragma unroll
+                for (int k = 0; k < kPre; ++k) {
+                    const int i = k * 64 + lane;
+                    const int r = i / SW, qq = i - r * SW;
+                    const int hy = y0 + r, hx = x0 + qq;
+                    pre[k] = (i < nel && hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hs + hx] : T(0);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = k * 64 + lane;
+                    wpre[k] = i < nA ? w[nA - 1 - i] : T(0);   // flipped atom
+                }
+#pragma unroll
+                for (int k = 0; k < kPre; ++k)
+                    if (k * 64 + lane < nel) Hs[k * 64 + lane] = pre[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k * 64 + lane < nA) Ws[k * 64 + lane] = wpre[k];
+            } else {
+                for (int i = lane; i < nel; i += 64) {
+                    const int r = i / SW, qq = i - r * SW;
+                    const int hy = y0 + r, hx = x0 + qq;
+                    Hs[i] = (hy < g.Hy && hx < g.Hx) ? h[(size_t)hy * g.Hs + hx] : T(0);
+                }
+                for (int i = lane; i < nA; i += 64) Ws[i] = w[nA - 1 - i];
+            }
+        }
+        __syncthreads();
+        if (has) {
+            for (int a = 0; a < g.Ay; ++a) {
+                const T *hr = Hs + (ty + a) * SW + tx;
+                const T *wr = Ws + a * g.Ax;
+#pragma unroll 8
+                for (int b = 0; b < g.Ax; ++b) acc += hr[b] * wr[b];
+            }
+        }
+    }
+    __syncthreads();
+    red[q * 64 + lane] = acc;
+    __syncthreads();
+    if (q == 0) {
+        T tot = red[lane];
+#pragma unroll
+        for (int k = 1; k < kSmallQ; ++k) tot += red[k * 64 + lane];   // wave order: fixed
+        const int y = y0 + ty, x = x0 + tx;
+        if (y < g.Dy && x < g.Dx) R[(((size_t)n * g.C + c) * g.Dy + y) * g.Dx + x] = tot;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // corr_W (H gradient): one block = one (n, m, tile of the shift plane); loop over channels, zero-padded V and R
 // tiles in LDS.  FUSED: H = (H * neg) / (pos + reg) in place instead of writing neg/pos.
@@ -670,6 +755,18 @@ int launch_reconstruct(const Geo &g, const void *W, const void *H, void *R, hipS
     if (lds > 64 * 1024) return TNMF_E_UNSUPPORTED;
     const size_t blocks = (size_t)g.N * g.C * t.tiles_y * t.tiles_x;
     if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
+    if (blocks < 64 && g.M >= kSmallQ && g.Dy > 1) {
+        // a small call (a mini-batch of a few samples): four waves per tile of 2 x 32 pixels, each on its own atoms
+        const int tiles_y = cdiv(g.Dy, kSmallTY), tiles_x = cdiv(g.Dx, kSmallTX);
+        const size_t lds_small = ((size_t)kSmallQ * ((size_t)(kSmallTY + g.Ay - 1) * (kSmallTX + g.Ax - 1) + (size_t)g.Ay * g.Ax) +
+                                  (size_t)kSmallQ * 64) * sizeof(T);
+        if (lds_small <= 64 * 1024) {
+            hipLaunchKernelGGL(k_reconstruct_small<T>, dim3((unsigned)((size_t)g.N * g.C * tiles_y * tiles_x)), dim3(kBlock),
+                               lds_small, s, g, tiles_y, tiles_x, (const T *)W, (const T *)H, (T *)R);
+            TNMF_LAUNCH_CHECK();
+            return TNMF_OK;
+        }
+    }
     hipLaunchKernelGGL(k_reconstruct<T>, dim3((unsigned)blocks), dim3(kBlock), lds, s, g, t, (const T *)W,
                        (const T *)H, (T *)R);
     TNMF_LAUNCH_CHECK();
