@@ -224,6 +224,12 @@ int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
                           void *R_scratch, void *acc, const tnmf_hip_op *ops, int n_ops, double eps, double sparsity,
                           void *stream);
 
+/* acc = a * acc + b * g over n_elems elements (a == 0: acc = b * g, whatever acc held): the blend of
+ * _accumulate_gradient_W (TransformInvariantNMF.py:444-455) for callers that drive the schedules step by step (several
+ * ranks: the collective sits between the gradient and this). */
+int tnmf_hip_axpby(tnmf_hip_ctx *ctx, int dtype, void *acc, const void *g, double a, double b, size_t n_elems,
+                   void *stream);
+
 /* Deterministic cross-rank reduction of the [neg | pos] buffer ("all-gather ... then sum in rank order"):
  *   out[i] = ((parts[0][i] + parts[1][i]) + parts[2][i]) + ...   for the n_parts buffers of n_elems elements that the
  * caller gathered one behind the other (rank order), in the element type.  Every rank that runs it on the same gathered

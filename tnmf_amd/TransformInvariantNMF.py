@@ -311,11 +311,14 @@ class TransformInvariantNMF:
         if local is not None and not lateral:
             # sum this rank's [neg | pos] over its batches, ONE all-reduce per epoch, then the fused MU
             total = None
+            blend = self._fused('blend_gradient_W')
             for batch in batches:
                 self._update_H(batch, **h_args)
                 part = local(self._V, self._W, self._H, batch)
                 if total is None:
                     total = part
+                elif blend is not None:
+                    blend(total, part, 1., 1.)
                 else:
                     total += part
             total = self._backend.all_reduce_gradient_W(total)

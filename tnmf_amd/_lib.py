@@ -22,7 +22,7 @@ EXPORTS = (
     'tnmf_hip_pad_H', 'tnmf_hip_fold_H', 'tnmf_hip_ctx_set_cache', 'tnmf_hip_ctx_invalidate',
     'tnmf_hip_ctx_set_split', 'tnmf_hip_ctx_h_row_stride', 'tnmf_hip_ctx_bind',
     'tnmf_hip_ctx_cache_counters', 'tnmf_hip_sum_parts',
-    'tnmf_hip_update_H_ex', 'tnmf_hip_run_schedule',
+    'tnmf_hip_update_H_ex', 'tnmf_hip_run_schedule', 'tnmf_hip_axpby',
 )
 
 MODES = {'valid': 0, 'full': 1, 'circular': 2, 'reflect': 3}
@@ -102,6 +102,7 @@ def load() -> ctypes.CDLL:
     lib.tnmf_hip_grad_W_fused.argtypes = [vp, gp, vp, vp, vp, vp, ci, vp, vp]
     lib.tnmf_hip_apply_W.argtypes = [vp, gp, vp, vp, cd, vp]
     lib.tnmf_hip_sum_parts.argtypes = [vp, ci, vp, ci, sz, vp, vp]
+    lib.tnmf_hip_axpby.argtypes = [vp, ci, vp, vp, cd, cd, sz, vp]
     lib.tnmf_hip_pad_H.argtypes = [vp, gp, ci, vp, vp, vp]
     lib.tnmf_hip_fold_H.argtypes = [vp, gp, ci, vp, vp, vp]
     for name in EXPORTS:

@@ -602,6 +602,14 @@ class HIP_Backend(Backend):
         kernels): its full-batch iterations go through run_schedule, i.e. the persistent schedule kernel."""
         return self.supports_schedules and H.shape[0] > 0 and H.numel() <= (1 << 18)
 
+    def blend_gradient_W(self, acc: torch.Tensor, g: torch.Tensor, a: float, b: float) -> torch.Tensor:
+        """acc = a * acc + b * g in place (a == 0: acc = b * g) -- the accumulators of the mini-batch schedules
+        (reference: TransformInvariantNMF.py:444-455) as a library kernel (tnmf_hip_axpby)."""
+        assert acc.is_contiguous() and g.is_contiguous() and acc.shape == g.shape and acc.dtype == g.dtype
+        _lib.check(self._lib.tnmf_hip_axpby(self._ctx, self._dtype_code, _ptr(acc), _ptr(g), float(a), float(b),
+                                            acc.numel(), self._stream()), 'tnmf_hip_axpby')
+        return acc
+
     def new_gradient_accumulator(self, W: torch.Tensor) -> torch.Tensor:
         return torch.empty((2,) + tuple(W.shape), dtype=W.dtype, device=W.device)
 

@@ -725,6 +725,15 @@ int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
     return TNMF_OK;
 }
 
+int tnmf_hip_axpby(tnmf_hip_ctx *ctx, int dtype, void *acc, const void *g, double a, double b, size_t n_elems,
+                   void *stream) {
+    if (!ctx) return TNMF_E_NULL;
+    if (dtype != 0 && dtype != 1) return TNMF_E_DTYPE;
+    if (n_elems > 0 && (!acc || !g)) return TNMF_E_NULL;
+    TNMF_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_axpby(ctx, dtype, acc, g, a, b, n_elems, static_cast<hipStream_t>(stream));
+}
+
 int tnmf_hip_sum_parts(tnmf_hip_ctx *ctx, int dtype, const void *parts, int n_parts, size_t n_elems, void *out,
                        void *stream) {
     if (!ctx) return TNMF_E_NULL;
