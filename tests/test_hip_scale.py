@@ -635,3 +635,19 @@ def test_schedules_in_one_call_match_the_batch_by_batch_path(algorithm, dtype, t
         dW, dH, gap = relmax(W, ref.W), relmax(H, ref.H), abs(E - ref.energy()) / ref.energy()
         assert dW < tol and dH < tol and gap < tol, (name, dW, dH, gap)
     assert relmax(got['one_call'][0], got['batch_by_batch'][0]) < (1e-13 if dtype == np.float64 else 1e-6)
+
+
+def test_inhibition_kernels_beyond_the_fused_kernel_fall_back_to_the_reference_lines():
+    """A 127-tap inhibition kernel (range 63) in float64 does not fit the LDS tile of the lateral-term kernel: the library
+    answers TNMF_E_UNSUPPORTED before touching H, the backend turns that into NotImplementedError and the front end walks
+    the reference's own lines (TransformInvariantNMF.py:253-269) on the backend's primitives -- same result."""
+    N, C, D, M, A = 2, 1, (40, 44), 4, (5, 5)
+    V = planted_V(N, C, D, M, A, seed=4, dtype=np.float64, density=0.05)
+    kw = dict(n_iterations=3, inhibition_strength=0.2, cross_atom_inhibition_strength=0.1)
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=M, atom_shape=A, backend='hip', inhibition_range=63)
+    nmf.fit(V, progress_callback=lambda *_: True, **kw)
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c', inhibition_range=63)
+    ref.fit(V, **kw)
+    assert relmax(nmf.W, ref.W) < 1e-10 and relmax(nmf.H, ref.H) < 1e-10

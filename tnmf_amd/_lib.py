@@ -45,6 +45,7 @@ class Op(ctypes.Structure):
 
 OP_UPDATE_H, OP_GRAD_W, OP_APPLY_W = 0, 1, 2
 
+E_UNSUPPORTED = -5
 E_STRIDE = -6   # TNMF_E_STRIDE: the kernel family of this call wants C-contiguous H
 
 

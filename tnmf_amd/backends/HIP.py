@@ -557,15 +557,23 @@ class HIP_Backend(Backend):
                         kp[0], kl[0], kp[1], kl[1], self._stream())
                 return rc, 'tnmf_hip_update_H_ex'
 
-            if self._mode != 0:
-                assert Hs.is_contiguous()
-                rc, where = run_ex(Hs, 0)
-                _lib.check(rc, where)
+            # (inhibition kernels too long for the lateral-term kernel's LDS tile, or planes beyond its 32-bit offsets: the
+            # library answers TNMF_E_UNSUPPORTED before it writes H, and the front end walks the reference's own lines)
+            try:
+                if self._mode != 0:
+                    assert Hs.is_contiguous()
+                    rc, where = run_ex(Hs, 0)
+                    _lib.check(rc, where)
+                    self._foreign_H()
+                elif self._call_H(Hs, True, run_ex):
+                    self._foreign_H()   # the library updated (and kept spectra of) a temporary copy
+                else:
+                    self._note_H_cache(Hs, W)
+            except _lib.TnmfHipError as exc:
                 self._foreign_H()
-            elif self._call_H(Hs, True, run_ex):
-                self._foreign_H()   # the library updated (and kept spectra of) a temporary copy
-            else:
-                self._note_H_cache(Hs, W)
+                if exc.code == _lib.E_UNSUPPORTED and lateral:
+                    raise NotImplementedError('lateral terms outside the fused kernel') from exc
+                raise
             return
         Rs = self._R_scratch[ls]
         self._validate_H_cache(Hs, W)

@@ -307,7 +307,8 @@ int launch_inhibition_t(int N, int M, int Hy, int ld, const void *H, void *E, co
     const size_t SH = kTY + 2 * ry, SW = (kTX + 2 * rx + 8) | 1;
     const size_t lds = (SH * SW + SH * (kTX + 1)) * sizeof(T);
     if (lds > 160 * 1024) return TNMF_E_UNSUPPORTED;
-
+    // (a plane is addressed through one buffer descriptor with 32-bit byte offsets)
+    if ((size_t)Hy * ld * sizeof(T) >= ((size_t)1 << 31)) return TNMF_E_UNSUPPORTED;
     Taps2<T> taps;
     for (int i = 0; i < kMaxTaps; ++i) {
         taps.ky[i] = i < ly ? (T)ky_host[ly - 1 - i] : T(0);
