@@ -312,7 +312,7 @@ def main():
     Hs = tuple(d + a - 1 for d, a in zip(cfg['D'], cfg['A']))
     h_bytes = 4.0 * n_local * cfg['M'] * float(np.prod(Hs))
     # row spectra of the FFT family: N*M*Hy*(Lx/2+1) complex64; 1-D signals: one row per (sample, atom)
-    Lx = next((L for L in (32, 48, 64, 96, 144, 192, 288, 384, 576) if L >= Hs[-1]), 0)
+    Lx = next((L for L in (32, 48, 64, 96, 144, 192, 270, 288, 384, 540, 576) if L >= Hs[-1]), 0)
     t_bytes = 8.0 * n_local * cfg['M'] * (Hs[0] if k == 2 else 1) * (Lx // 2 + 1)
 
     # samples one kernel launch processes, as a fraction of the rank's samples (Cyclic-MU launches work on one batch)

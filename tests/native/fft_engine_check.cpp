@@ -103,8 +103,10 @@ int main() {
     bad += report<96>();
     bad += report<144>();
     bad += report<192>();
+    bad += report<270>();
     bad += report<288>();
     bad += report<384>();
+    bad += report<540>();
     bad += report<576>();
     printf(bad ? "FAILED\n" : "OK\n");
     return bad;

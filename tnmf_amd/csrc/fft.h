@@ -46,8 +46,10 @@ TNMF_FFT_DECL(64);
 TNMF_FFT_DECL(96);
 TNMF_FFT_DECL(144);
 TNMF_FFT_DECL(192);
+TNMF_FFT_DECL(270);
 TNMF_FFT_DECL(288);
 TNMF_FFT_DECL(384);
+TNMF_FFT_DECL(540);
 TNMF_FFT_DECL(576);
 #undef TNMF_FFT_DECL
 

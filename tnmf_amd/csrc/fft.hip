@@ -16,11 +16,21 @@
 
 namespace {
 
-const int kLens[] = {32, 48, 64, 96, 144, 192, 288, 384, 576};
+// Transform lengths.  Along x (row transforms) two more lengths exist: 270 and 540 store 136 / 271 frequencies = 8.5 / 17
+// segments of 16 where 288 / 576 store 145 / 289 = 9.06 / 18.06 -- one whole 128-byte segment per spectrum row less for
+// the shift widths of the BASELINE geometries (267, 527): a tenth less of every stream of spectra and of every
+// contraction's work.  (The column kernels deal whole tiles over their threads and are instantiated for the first list only.)
+const int kLensY[] = {32, 48, 64, 96, 144, 192, 288, 384, 576};
+const int kLensX[] = {32, 48, 64, 96, 144, 192, 270, 288, 384, 540, 576};
 constexpr int kMixMaxGroups = 128;   // partial-sum slots of the mixed W-gradient kernel (Gn / Gp)
 
-int pick_len(int h, int dtype) {
-    for (int L : kLens)
+int pick_len(int h, int dtype, bool along_x) {
+    if (along_x) {
+        for (int L : kLensX)
+            if (L >= h && (dtype == 0 || L <= 288)) return L;
+        return 0;
+    }
+    for (int L : kLensY)
         if (L >= h && (dtype == 0 || L <= 288)) return L;
     return 0;
 }
@@ -33,8 +43,10 @@ fft_run_fn lookup(int L) {
         case 96: return fft_run_96;
         case 144: return fft_run_144;
         case 192: return fft_run_192;
+        case 270: return fft_run_270;
         case 288: return fft_run_288;
         case 384: return fft_run_384;
+        case 540: return fft_run_540;
         case 576: return fft_run_576;
         default: return nullptr;
     }
@@ -64,8 +76,8 @@ void sample_groups(const Geo &g, int tiles, int *ngroups, int *nper) {
 }
 
 bool make_layout(const Geo &gfull, const Geo &g, int dtype, Lay *l) {
-    l->Ly = pick_len(g.Hy, dtype);
-    l->Lx = pick_len(g.Hx, dtype);
+    l->Ly = pick_len(g.Hy, dtype, false);
+    l->Lx = pick_len(g.Hx, dtype, true);
     if (!l->Ly || !l->Lx) return false;
     l->rowf = lookup(l->Lx);
     l->colf = lookup(l->Ly);
@@ -510,9 +522,9 @@ bool fft_has(const Geo &g, int dtype) {
         // 1-D signals: the row-transform half of the family alone (float32, up to three channels): reconstruct and the W
         // gradient are pointwise products of row spectra; the H update stays on the direct kernels (fft_grad_H /
         // fft_update_H refuse 1-D problems)
-        return pick_len(g.Hx, dtype) != 0 && mixed_has_reconstruct(g, dtype) && mixed_has_grad_W(g, dtype);
+        return pick_len(g.Hx, dtype, true) != 0 && mixed_has_reconstruct(g, dtype) && mixed_has_grad_W(g, dtype);
     }
-    return pick_len(g.Hy, dtype) != 0 && pick_len(g.Hx, dtype) != 0;
+    return pick_len(g.Hy, dtype, false) != 0 && pick_len(g.Hx, dtype, true) != 0;
 }
 
 void fft_bind(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H, const void *V) {

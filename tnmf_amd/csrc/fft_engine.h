@@ -88,6 +88,24 @@ struct Dft<T, 4> {
     }
 };
 
+template <typename T>
+struct Dft<T, 5> {
+    static TNMF_HD void run(cplx<T> *v) {
+        const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;   // cos(2 pi / 5), cos(4 pi / 5)
+        const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;    // sin(2 pi / 5), sin(4 pi / 5)
+        const cplx<T> a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+        const cplx<T> t1 = {v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y};
+        const cplx<T> t2 = {v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y};
+        const cplx<T> u1 = {s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y};
+        const cplx<T> u2 = {s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y};
+        v[0] = cadd(v[0], cadd(a1, a2));
+        v[1] = {t1.x + u1.y, t1.y - u1.x};   // t1 - i u1
+        v[4] = {t1.x - u1.y, t1.y + u1.x};   // t1 + i u1
+        v[2] = {t2.x + u2.y, t2.y - u2.x};
+        v[3] = {t2.x - u2.y, t2.y + u2.x};
+    }
+};
+
 // N = RA*RB by one Cooley-Tukey split with compile-time twiddles (loops unroll, constants fold)
 template <typename T, int RA, int RB>
 struct DftComposite {
@@ -135,6 +153,8 @@ template <typename T>
 struct Dft<T, 8> : DftComposite<T, 2, 4> {};
 template <typename T>
 struct Dft<T, 9> : DftComposite<T, 3, 3> {};
+template <typename T>
+struct Dft<T, 10> : DftComposite<T, 2, 5> {};
 template <typename T>
 struct Dft<T, 12> : DftComposite<T, 3, 4> {};
 template <typename T>
@@ -259,8 +279,10 @@ TNMF_FFT_PLAN(64, 4, 4, 4);
 TNMF_FFT_PLAN(96, 4, 4, 6);
 TNMF_FFT_PLAN(144, 4, 6, 6);
 TNMF_FFT_PLAN(192, 4, 6, 8);
+TNMF_FFT_PLAN(270, 5, 6, 9);   // (row direction only: 136 stored frequencies = 8.5 segments of 16 where 288 has 145 = 9.06)
 TNMF_FFT_PLAN(288, 6, 6, 8);
 TNMF_FFT_PLAN(384, 6, 8, 8);
+TNMF_FFT_PLAN(540, 6, 9, 10);  // (row direction only: 271 stored frequencies = 17 segments where 576 has 289 = 18.06)
 TNMF_FFT_PLAN(576, 8, 8, 9);
 #undef TNMF_FFT_PLAN
 
