@@ -20,7 +20,9 @@ template <int L>
 struct LenCfg {
     static constexpr int col_tile = L > 384 ? 8 : 16;   // kx columns per column-kernel tile (a power of two); the long
                                                         // transforms take narrow tiles to keep the per-thread share at 9
-    static constexpr int col_threads = L > 192 ? 512 : 256;
+    // (270 and 540: 270 * 16 = 540 * 8 = 4320 tile elements = 2^5 * 3^3 * 5: 480 threads take 9 each)
+    static constexpr int col_threads = (L == 270 || L == 540) ? 480 : (L > 192 ? 512 : 256);
+    static_assert((L * col_tile) % col_threads == 0 && (L * 16) % col_threads == 0, "whole tile elements per thread");
     static constexpr int col_elems = L * col_tile / col_threads;   // tile elements per thread
     static constexpr int row_pairs = L > 288 ? 8 : 16;
     static constexpr int row_threads = 256;
