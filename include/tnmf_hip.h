@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TNMF_HIP_ABI_VERSION 5
+#define TNMF_HIP_ABI_VERSION 6
 
 enum {
     TNMF_OK = 0,
@@ -44,12 +44,12 @@ enum {
 typedef struct tnmf_hip_ctx tnmf_hip_ctx;
 
 typedef struct {
-    int ndim;  /* 1 or 2 shift axes */
+    int ndim;  /* 1, 2 or 3 shift axes (3: volumes, axes z, y, x -- see "Volumes" below) */
     int N;     /* samples in this call (mini-batch slice length) */
     int M;     /* atoms */
     int C;     /* channels */
-    int D[2];  /* sample shape; ndim == 1 uses D[0] only */
-    int A[2];  /* atom shape;   ndim == 1 uses A[0] only */
+    int D[3];  /* sample shape; the first ndim entries are used */
+    int A[3];  /* atom shape;   the first ndim entries are used */
     int dtype; /* 0 = f32, 1 = f64 */
     /* Row stride of H in elements; 0 (or the shift width D[last] + A[last] - 1) = C-contiguous, as the reference's arrays
      * are.  A larger value describes activations whose rows are padded to whole cache lines: H[n,m,y,x] at
@@ -157,6 +157,22 @@ int tnmf_hip_energy(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V,
 int tnmf_hip_convolve_multi_1d(tnmf_hip_ctx *ctx, int dtype, int ndim, size_t rows, const int *shape,
                                const void *in, void *out, void *tmp, const double *kernel0, int len0,
                                const double *kernel1, int len1, void *stream);
+
+/* One axis of the same convolution, for any number of shift axes: arr viewed as [rows][len][inner], convolved along
+ * `len` (zero-padded 'same', odd-length kernel of at most 127 taps, host doubles), out != in.  convolve_multi_1d over k
+ * axes is k calls in the reference's order, first shift axis first (_NumPyBackend.py:60-62), ping-ponging two buffers --
+ * how the three axes of a volume are done. */
+int tnmf_hip_convolve_axis(tnmf_hip_ctx *ctx, int dtype, size_t rows, int len, size_t inner, const void *in, void *out,
+                           const double *kernel, int klen, void *stream);
+
+/* ---- Volumes (ndim == 3) -----------------------------------------------------------------------------------------
+ * The reference takes any number of shift axes in NumPy (tnmf/backends/NumPy.py:69-132 contracts over all of them) and
+ * one to three in PyTorch (tnmf/backends/PyTorch.py:13-17: conv1d / conv2d / conv3d).  With ndim == 3 the entry points
+ * tnmf_hip_reconstruct, _grad_H, _grad_W, _grad_W_fused, _update_H, _apply_W, _normalize_W, _energy, _pad_H, _fold_H and
+ * _ctx_reserve run direct kernels of their own (float32 and float64, C-contiguous activations: h_row_stride 0 or the
+ * shift width); _mu_update, _axpby, _sum_parts and _convolve_axis do not look at the geometry.  tnmf_hip_update_H_ex and
+ * tnmf_hip_run_schedule answer TNMF_E_UNSUPPORTED (the caller composes those steps from the entry points above);
+ * tnmf_hip_ctx_bind is accepted and has nothing to do.  tnmf_hip_ctx_last_path reads "volume". */
 
 /* ---- reconstruction modes other than 'valid' --------------------------------------------------------------------
  * Every mode of the reference is a 'valid' reconstruction of padded activations (padding table:

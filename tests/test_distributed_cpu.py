@@ -39,6 +39,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn(fn, args_of_port, nprocs=2):
+    """mp.spawn on a fresh port; the port is probed and released before the ranks bind it, so a rare race with another
+    process's ephemeral port gets one more attempt on another port."""
+    for attempt in range(2):
+        try:
+            mp.spawn(fn, args=args_of_port(_free_port()), nprocs=nprocs, join=True)
+            return
+        except Exception:   # noqa: BLE001
+            if attempt:
+                raise
+
+
 def _worker(rank, world, port, mode, out):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -67,7 +79,7 @@ def _worker(rank, world, port, mode, out):
 def test_two_ranks_match_single_process(tmp_path, mode):
     from oracle_backend import OracleBackend
     from tnmf_amd.TransformInvariantNMF import MiniBatchAlgorithm, TransformInvariantNMF
-    mp.spawn(_worker, args=(2, _free_port(), mode, str(tmp_path)), nprocs=2, join=True)
+    _spawn(_worker, lambda port: (2, port, mode, str(tmp_path)))
     r0, r1 = (np.load(tmp_path / f'rank{r}.npz') for r in range(2))
 
     rng = np.random.default_rng(7)
@@ -101,7 +113,7 @@ def _gather_worker(rank, world, port, out):
 
 def test_all_gather_is_in_rank_order(tmp_path):
     """The gather of the 'ordered' reduction (HIP_Backend(reduce='ordered')): [world, *shape], rank r at index r."""
-    mp.spawn(_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _spawn(_gather_worker, lambda port: (2, port, str(tmp_path)))
     want = np.stack([np.arange(6, dtype=np.float32).reshape(2, 3) + 10 * r for r in range(2)])
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f'gather{r}.npy'), want)

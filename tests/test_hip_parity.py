@@ -73,7 +73,7 @@ def test_primitives_against_reference_golden(case, dtype, tol, path):
     assert relmax(be.to_ndarray(be.partial_reconstruct(W, H, M - 1)), g['R_partial_last']) < tol
     kern = orc.inhibition_kernels(tuple(a - 1 for a in A))
     assert relmax(be.to_ndarray(be.convolve_multi_1d(H, kern, tuple(range(-k, 0)))), g['inhibition_conv']) < tol
-    assert be.last_path in ('generic', 'mfma', 'split')
+    assert be.last_path in ('generic', 'mfma', 'split', 'volume')
 
 
 @pytest.mark.parametrize('case', CASES[:3], ids=[os.path.basename(p)[11:-4] for p in CASES[:3]])

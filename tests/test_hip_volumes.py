@@ -1,0 +1,172 @@
+"""
+Three shift axes (volumes) through backend 'hip' -- the reference takes them in NumPy (backends/NumPy.py:69-132 is
+k-generic) and in PyTorch (backends/PyTorch.py:13-17, conv3d).  The golden vectors of the genuine reference backend
+(tests/golden/primitives_3d_*.npz, modes_*_3d.npz) run through test_hip_parity.py with the other fixtures; here: the
+kernels of tnmf_amd/csrc/volume.hip against the oracle on ragged shapes and slices, the fused half steps, and whole
+fits (every reconstruction mode, lateral terms, a mini-batch schedule) against the oracle's loop.
+The reference holds no known-answer energy for three shift axes (its tests stop at 2-D): the fits are pinned by the
+oracle, which the 3-D golden vectors pin in turn (tests/test_oracle_pinning.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tnmf_oracle as orc
+from tnmf_amd.TransformInvariantNMF import MiniBatchAlgorithm, TransformInvariantNMF
+from tnmf_amd.backends.HIP import HIP_Backend
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+def relmax(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    scale = np.abs(want).max()
+    return np.abs(np.asarray(got, dtype=np.float64) - want).max() / (scale if scale > 0 else 1.0)
+
+
+SHAPES = [
+    # N, C, D, M, A     (x longer than a wave, one-voxel atoms, atoms as large as the sample, a single sample)
+    (2, 1, (5, 6, 70), 3, (2, 3, 4)),
+    (3, 2, (4, 9, 7), 5, (3, 1, 2)),
+    (1, 1, (3, 4, 5), 2, (3, 4, 5)),
+    (2, 3, (6, 5, 4), 4, (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-10), (np.float32, 2e-5)], ids=['f64', 'f32'])
+@pytest.mark.parametrize('shape', SHAPES, ids=[f'{s[0]}x{s[1]}x{"x".join(map(str, s[2]))}_m{s[3]}_a{"x".join(map(str, s[4]))}' for s in SHAPES])
+def test_volume_primitives_against_oracle(shape, dtype, tol):
+    N, C, D, M, A = shape
+    rng = np.random.default_rng(N * 100 + M)
+    V = rng.random((N, C) + D)
+    Wn = rng.random((M, C) + A)
+    Wn /= Wn.sum(axis=(-3, -2, -1), keepdims=True)
+    Hn = rng.random((N, M) + tuple(d + a - 1 for d, a in zip(D, A)))
+    be = HIP_Backend()
+    np.random.seed(1)
+    be.initialize(V.astype(dtype), A, M, None, (-3, -2, -1))
+    W, H = dev(Wn, dtype), dev(Hn, dtype)
+    assert relmax(be.to_ndarray(be.reconstruct(W, H)), orc.reconstruct(Wn, Hn)) < tol
+    assert be.last_path == 'volume'
+    for s in (slice(None), slice(0, 0), slice(N - 1, N)):
+        on, op = orc.gradient_H(V, Wn, Hn, s)
+        neg, pos = be.reconstruction_gradient_H(V, W, H, s)
+        assert tuple(neg.shape) == on.shape
+        if on.size:
+            assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+        on, op = orc.gradient_W(V, Wn, Hn, s)
+        neg, pos = be.reconstruction_gradient_W(V, W, H, s)
+        assert relmax(be.to_ndarray(neg), on) < tol and relmax(be.to_ndarray(pos), op) < tol
+    assert abs(be.reconstruction_energy(V, W, H) - orc.energy(V, Wn, Hn)) / orc.energy(V, Wn, Hn) < tol
+    # normalisation over the three atom axes
+    Wr = dev(rng.random(Wn.shape), dtype)
+    want = be.to_ndarray(Wr).astype(np.float64)
+    want /= want.sum(axis=(-3, -2, -1), keepdims=True)
+    be.normalize(Wr, (-3, -2, -1))
+    assert relmax(be.to_ndarray(Wr), want) < tol
+    # fused half steps == primitives + MU (TransformInvariantNMF.py:232-271)
+    Hf = dev(Hn, dtype)
+    be.fused_update_H(V, W, Hf, slice(None), sparsity=0.1, eps=1e-9)
+    on, op = orc.gradient_H(V, Wn, Hn)
+    assert relmax(be.to_ndarray(Hf), Hn * on / (op + 0.1 + 1e-9)) < 5 * tol
+    Wf = dev(Wn, dtype)
+    be.fused_update_W(V, Wf, H, slice(None), eps=1e-9)
+    on, op = orc.gradient_W(V, Wn, Hn)
+    want = Wn * on / (op + 1e-9)
+    want /= want.sum(axis=(-3, -2, -1), keepdims=True)
+    assert relmax(be.to_ndarray(Wf), want) < 5 * tol
+    # the W gradient sums in a fixed order: the same bits from launch to launch
+    a = be.to_ndarray(be.local_gradient_W(V, W, H))
+    b = be.to_ndarray(be.local_gradient_W(V, W, H))
+    assert np.array_equal(a, b)
+
+
+def _volume(seed=3, N=3, C=2, D=(8, 9, 10)):
+    rng = np.random.default_rng(seed)
+    V = rng.random((N, C) + D)
+    V[:, :, 2:5, 3:6, 4:8] += 2.0   # a block every sample shares
+    return V
+
+
+@pytest.mark.parametrize('mode', ['valid', 'full', 'circular', 'reflect'])
+def test_volume_fit_matches_oracle_f64(mode):
+    V = _volume()
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=3, atom_shape=(3, 2, 4), backend='hip', reconstruction_mode=mode)
+    nmf.fit(V, n_iterations=6, sparsity_H=0.05)
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=3, atom_shape=(3, 2, 4), reconstruction_mode=mode)
+    ref.fit(V, n_iterations=6, sparsity_H=0.05)
+    assert nmf.H.shape == ref.H.shape
+    np.testing.assert_allclose(nmf.W, ref.W, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(nmf.H, ref.H, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(nmf.R, ref.R, rtol=1e-9, atol=1e-12)
+    assert np.isclose(nmf._energy_function(), ref.energy(), rtol=1e-10)
+
+
+def test_volume_fit_with_lateral_terms_matches_oracle_f64():
+    """Inhibition and cross-atom inhibition: three passes of tnmf_hip_convolve_axis, then the update kernel."""
+    V = _volume(seed=5)
+    kw = dict(n_iterations=5, sparsity_H=0.02, inhibition_strength=0.1, cross_atom_inhibition_strength=0.05)
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=3, atom_shape=(2, 3, 3), backend='hip')
+    nmf.fit(V, **kw)
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=3, atom_shape=(2, 3, 3))
+    ref.fit(V, **kw)
+    np.testing.assert_allclose(nmf.W, ref.W, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(nmf.H, ref.H, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('algorithm', [MiniBatchAlgorithm.Cyclic_MU, MiniBatchAlgorithm.ASG_MU, MiniBatchAlgorithm.GSAG_MU])
+def test_volume_minibatch_schedules_match_oracle_f64(algorithm):
+    V = _volume(seed=7, N=5, C=1, D=(6, 7, 8))
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=2, atom_shape=(2, 2, 3), backend='hip')
+    nmf.fit(V, algorithm=algorithm, batch_size=2, n_epochs=3)
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=2, atom_shape=(2, 2, 3))
+    ref.fit(V, algorithm=algorithm, batch_size=2, n_epochs=3)
+    np.testing.assert_allclose(nmf.W, ref.W, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(nmf.H, ref.H, rtol=1e-9, atol=1e-12)
+
+
+def test_volume_fit_f32_within_the_parity_bar():
+    """float32 against the float64 oracle: W, H and the energy within 1e-5 (BASELINE.json's bar) after 5 iterations."""
+    V = _volume(seed=9, N=4, C=1, D=(10, 12, 33))
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=4, atom_shape=(3, 3, 5), backend='hip')
+    nmf.fit(V.astype(np.float32), n_iterations=5)
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=4, atom_shape=(3, 3, 5))
+    ref.fit(V.astype(np.float32).astype(np.float64), n_iterations=5)
+    assert relmax(nmf.W, ref.W) < 1e-5 and relmax(nmf.H, ref.H) < 1e-5
+    assert abs(nmf._energy_function() - ref.energy()) / ref.energy() < 1e-5
+
+
+def test_volume_steps_outside_the_library_answer_unsupported():
+    """tnmf_hip_update_H_ex / tnmf_hip_run_schedule cover one and two shift axes; for volumes they refuse before touching
+    anything and the front end composes the step (the fits above)."""
+    import ctypes
+    from tnmf_amd import _lib
+    V = _volume(N=2, C=1, D=(4, 5, 6)).astype(np.float32)
+    be = HIP_Backend()
+    np.random.seed(0)
+    W, H = be.initialize(V, (2, 2, 2), 2, None, (-3, -2, -1))
+    before = be.to_ndarray(H).copy()
+    g = be._geom(2, 2)
+    one = (ctypes.c_double * 1)(1.0)
+    rc = be._lib.tnmf_hip_update_H_ex(be._ctx, ctypes.byref(g), 0, be._V_dev.data_ptr(), W.data_ptr(), H.data_ptr(), None,
+                                      1e-9, 0.0, 0.1, 0.0, one, 1, one, 1, None)
+    assert rc == _lib.E_UNSUPPORTED
+    acc = be.new_gradient_accumulator(W)
+    ops = (_lib.Op * 1)()
+    rc = be._lib.tnmf_hip_run_schedule(be._ctx, ctypes.byref(g), be._V_dev.data_ptr(), W.data_ptr(), H.data_ptr(), None,
+                                       acc.data_ptr(), ops, 1, 1e-9, 0.0, None)
+    assert rc == _lib.E_UNSUPPORTED
+    assert np.array_equal(be.to_ndarray(H), before)
+    assert not be.supports_schedules

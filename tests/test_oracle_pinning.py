@@ -52,7 +52,9 @@ def test_primitives_match_reference_backend(path):
         neg, pos = orc.gradient_W_fft(V, W, H)
         np.testing.assert_allclose(neg, g['neg_W'], rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(pos, g['pos_W'], rtol=1e-9, atol=1e-9)
-    # third: the C flavour (oracle/tnmf_oracle_c.c), in float64 and in float32 (double accumulation)
+    # third: the C flavour (oracle/tnmf_oracle_c.c; one and two shift axes), in float64 and in float32 (double accumulation)
+    if k == 3:
+        return
     np.testing.assert_allclose(orc.reconstruct(W, H, 'c'), g['R'], **tol)
     neg, pos = orc.gradient_H(V, W, H, s, 'c')
     np.testing.assert_allclose(neg, g['neg_H'], **tol)
@@ -191,7 +193,7 @@ def test_mode_primitives_match_reference_backend(path):
     V, W, H, s = g['V'], g['W'], g['H'], _slice(g)
     assert H.shape[2:] == orc.transform_shape(V.shape[2:], W.shape[2:], mode)
     tol = dict(rtol=1e-12, atol=1e-12)
-    for impl in ('contract', 'c'):
+    for impl in ('contract', 'c') if W.ndim - 2 < 3 else ('contract',):   # (the C flavour: one and two shift axes)
         np.testing.assert_allclose(orc.reconstruct(W, H, impl, mode), g['R'], **tol)
         neg, pos = orc.gradient_H(V, W, H, s, impl, mode)
         np.testing.assert_allclose(neg, g['neg_H'], **tol)

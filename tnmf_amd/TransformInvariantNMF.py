@@ -160,15 +160,17 @@ class TransformInvariantNMF:
         lateral = inhibition > 0 or cross_inhibition > 0
         fused = self._fused('fused_update_H')
         if fused is not None:
-            if not lateral:
-                fused(self._V, self._W, self._H, s, sparsity=sparsity, eps=self.eps)
-                return
             try:
-                fused(self._V, self._W, self._H, s, sparsity=sparsity, eps=self.eps, inhibition=inhibition,
-                      cross_inhibition=cross_inhibition, inhibition_kernels=self._inhibition_kernels_1D)
+                if lateral:
+                    fused(self._V, self._W, self._H, s, sparsity=sparsity, eps=self.eps, inhibition=inhibition,
+                          cross_inhibition=cross_inhibition, inhibition_kernels=self._inhibition_kernels_1D)
+                else:
+                    fused(self._V, self._W, self._H, s, sparsity=sparsity, eps=self.eps)
                 return
             except NotImplementedError:
-                pass   # (e.g. inhibition kernels longer than the backend's fused kernel takes: the lines below)
+                # (inhibition kernels longer than the backend's fused kernel takes; lateral terms or reconstruction modes
+                # of volumes: nothing has been written, the reference's own lines below do the step)
+                pass
         neg, pos = self._backend.reconstruction_gradient_H(self._V, self._W, self._H, s)
         Hs = self._H[s]
         assert neg.shape == Hs.shape and pos.shape == Hs.shape

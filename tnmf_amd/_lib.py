@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libtnmf_hip.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/tnmf_hip.h declares
 EXPORTS = (
@@ -22,7 +22,7 @@ EXPORTS = (
     'tnmf_hip_pad_H', 'tnmf_hip_fold_H', 'tnmf_hip_ctx_set_cache', 'tnmf_hip_ctx_invalidate',
     'tnmf_hip_ctx_set_split', 'tnmf_hip_ctx_h_row_stride', 'tnmf_hip_ctx_bind',
     'tnmf_hip_ctx_cache_counters', 'tnmf_hip_sum_parts',
-    'tnmf_hip_update_H_ex', 'tnmf_hip_run_schedule', 'tnmf_hip_axpby',
+    'tnmf_hip_update_H_ex', 'tnmf_hip_run_schedule', 'tnmf_hip_axpby', 'tnmf_hip_convolve_axis',
 )
 
 MODES = {'valid': 0, 'full': 1, 'circular': 2, 'reflect': 3}
@@ -33,7 +33,7 @@ PATHS = {'auto': 0, 'generic': 1, 'mfma': 2, 'fft': 3, 'hybrid': 4, 'split': 5}
 class Geom(ctypes.Structure):
     """tnmf_hip_geom"""
     _fields_ = [('ndim', ctypes.c_int), ('N', ctypes.c_int), ('M', ctypes.c_int), ('C', ctypes.c_int),
-                ('D', ctypes.c_int * 2), ('A', ctypes.c_int * 2), ('dtype', ctypes.c_int),
+                ('D', ctypes.c_int * 3), ('A', ctypes.c_int * 3), ('dtype', ctypes.c_int),
                 ('h_row_stride', ctypes.c_int)]
 
 
@@ -96,6 +96,7 @@ def load() -> ctypes.CDLL:
     lib.tnmf_hip_energy.argtypes = [vp, gp, vp, vp, vp, ctypes.POINTER(cd), vp]
     lib.tnmf_hip_convolve_multi_1d.argtypes = [vp, ci, ci, sz, ctypes.POINTER(ci), vp, vp, vp,
                                                ctypes.POINTER(cd), ci, ctypes.POINTER(cd), ci, vp]
+    lib.tnmf_hip_convolve_axis.argtypes = [vp, ci, sz, ci, sz, vp, vp, ctypes.POINTER(cd), ci, vp]
     lib.tnmf_hip_update_H.argtypes = [vp, gp, vp, vp, vp, vp, ci, cd, cd, vp]
     lib.tnmf_hip_update_H_ex.argtypes = [vp, gp, ci, vp, vp, vp, vp, cd, cd, cd, cd, ctypes.POINTER(cd), ci,
                                          ctypes.POINTER(cd), ci, vp]
@@ -125,8 +126,8 @@ def check(code: int, where: str) -> None:
 def make_geom(n: int, m: int, c: int, sample_shape: Sequence[int], atom_shape: Sequence[int], dtype_code: int,
               h_row_stride: int = 0) -> Geom:
     k = len(atom_shape)
-    if k not in (1, 2) or len(sample_shape) != k:
-        raise NotImplementedError('the hip backend supports 1 or 2 shift dimensions')
+    if k not in (1, 2, 3) or len(sample_shape) != k:
+        raise NotImplementedError('the hip backend supports 1, 2 or 3 shift dimensions')
     g = Geom()
     g.ndim, g.N, g.M, g.C, g.dtype = k, int(n), int(m), int(c), int(dtype_code)
     for i in range(k):

@@ -337,8 +337,8 @@ class HIP_Backend(Backend):
     def _initialize_matrices(self, V: np.ndarray, atom_shape, n_atoms: int, W=None, axes_W_normalization=None):
         if V.dtype not in _DTYPES:
             raise TypeError(f'the hip backend computes in float32 or float64, V has dtype {V.dtype}')
-        if len(atom_shape) not in (1, 2):
-            raise NotImplementedError('the hip backend supports 1 or 2 shift dimensions')
+        if len(atom_shape) not in (1, 2, 3):   # (3: volumes, on the direct kernels of tnmf_amd/csrc/volume.hip)
+            raise NotImplementedError('the hip backend supports 1, 2 or 3 shift dimensions')
         self._torch_dtype, self._dtype_code = _DTYPES[V.dtype]
         N = self.n_samples
         self._foreign_H()
@@ -495,9 +495,21 @@ class HIP_Backend(Backend):
         if not arr.is_contiguous():   # (e.g. row-padded activations)
             arr = arr.contiguous()
         out = torch.empty_like(arr)
-        tmp = torch.empty_like(arr) if k == 2 else None
+        tmp = torch.empty_like(arr) if k >= 2 else None
         ks = [np.ascontiguousarray(kk, dtype=np.float64) for kk in kernels]
         kp = [kk.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for kk in ks]
+        if k == 3:
+            # volumes: one axis per call, first shift axis first (_NumPyBackend.py:60-62), ping-ponging two buffers so
+            # that the third pass lands in `out`
+            shp = [int(x) for x in arr.shape]
+            src, bufs = arr, [out, tmp, out]
+            for i in range(3):
+                rows, inner = int(np.prod(shp[:2 + i])), int(np.prod(shp[3 + i:]))
+                _lib.check(self._lib.tnmf_hip_convolve_axis(
+                    self._ctx, self._dtype_code, rows, shp[2 + i], inner, _ptr(src), _ptr(bufs[i]), kp[i], len(ks[i]),
+                    self._stream()), 'tnmf_hip_convolve_axis')
+                src = bufs[i]
+            return out
         shape = (ctypes.c_int * 2)(*[int(x) for x in arr.shape[-k:]] + [1] * (2 - k))
         rows = int(np.prod(arr.shape[:-k]))
         _lib.check(self._lib.tnmf_hip_convolve_multi_1d(
@@ -538,6 +550,8 @@ class HIP_Backend(Backend):
         lateral = inhibition > 0 or cross_inhibition > 0
         if self._mode != 0 or lateral:
             k = len(self.atom_shape)
+            if k == 3:   # (tnmf_hip_update_H_ex covers one and two shift axes: the front end composes the step for volumes)
+                raise NotImplementedError('lateral terms / reconstruction modes of volumes outside the fused kernel')
             ks = [np.ascontiguousarray(kk, dtype=np.float64) for kk in (inhibition_kernels or ())]
             if lateral and len(ks) != k:
                 raise ValueError('one inhibition kernel per shift axis')
@@ -603,7 +617,7 @@ class HIP_Backend(Backend):
     def supports_schedules(self) -> bool:
         """tnmf_hip_run_schedule covers 'valid' mode on one device (with several ranks the W gradient must cross the
         collective between two of its operations)."""
-        return self._mode == 0 and self._world == 1
+        return self._mode == 0 and self._world == 1 and len(self.atom_shape or ()) < 3
 
     def prefers_schedule(self, H: torch.Tensor) -> bool:
         """A whole problem this small is bound by launch latency (BASELINE config 1: 0.34 ms per iteration for 0.1 ms of

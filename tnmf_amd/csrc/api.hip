@@ -9,6 +9,7 @@
 #include "generic.h"
 #include "mfma.h"
 #include "split.h"
+#include "volume.h"
 
 namespace {
 
@@ -40,6 +41,39 @@ int to_geo(const tnmf_hip_geom *in, Geo *g) {
 }
 
 inline size_t esize(int dtype) { return dtype == 0 ? 4 : 8; }
+
+// three shift axes (volumes): a kernel family of its own (volume.hip); H is C-contiguous there
+inline bool is_vol(const tnmf_hip_geom *in) { return in && in->ndim == 3; }
+
+int to_vol(const tnmf_hip_geom *in, Vol *v) {
+    if (!in) return TNMF_E_NULL;
+    if (in->dtype != 0 && in->dtype != 1) return TNMF_E_DTYPE;
+    v->N = in->N;
+    v->M = in->M;
+    v->C = in->C;
+    if (v->N < 0 || v->M <= 0 || v->C <= 0) return TNMF_E_GEOM;
+    for (int i = 0; i < 3; ++i) {
+        v->D[i] = in->D[i];
+        v->A[i] = in->A[i];
+        if (v->D[i] <= 0 || v->A[i] <= 0) return TNMF_E_GEOM;
+        v->H[i] = v->D[i] + v->A[i] - 1;
+    }
+    if (in->h_row_stride > 0 && in->h_row_stride != v->H[2]) return TNMF_E_STRIDE;
+    return TNMF_OK;
+}
+inline size_t vol_vox(const Vol &v) { return (size_t)v.D[0] * v.D[1] * v.D[2]; }
+inline size_t vol_hvox(const Vol &v) { return (size_t)v.H[0] * v.H[1] * v.H[2]; }
+inline size_t vol_avox(const Vol &v) { return (size_t)v.A[0] * v.A[1] * v.A[2]; }
+// the dictionary of a volume problem as the (M, C, flattened atom) rows the normalisation kernel works on
+inline Geo vol_dict_geo(const Vol &v) {
+    Geo g = {};
+    g.N = v.N;
+    g.M = v.M;
+    g.C = v.C;
+    g.Ay = v.A[0] * v.A[1];
+    g.Ax = v.A[2];
+    return g;
+}
 
 // scratch layout: [R (N*C*D elements)] [split-K partials (doubles)] [energy partials + result (doubles)]
 struct Scratch {
@@ -154,6 +188,28 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
         if (_rc != TNMF_OK) return _rc; \
     } while (0)
 
+#define VOL_ENTER(ctx, geom)                               \
+    if (!(ctx)) return TNMF_E_NULL;                        \
+    Vol v;                                                 \
+    {                                                      \
+        const int _rc = to_vol((geom), &v);                \
+        if (_rc != TNMF_OK) return _rc;                    \
+    }                                                      \
+    const int dtype = (geom)->dtype;                       \
+    hipStream_t s = static_cast<hipStream_t>(stream);      \
+    TNMF_HIP_TRY(hipSetDevice((ctx)->device));             \
+    (ctx)->last_path = "volume";
+
+// scratch of a volume call: [R of the slice | energy partials + result]
+int vol_scratch(tnmf_hip_ctx *ctx, const Vol &v, int dtype, void **R, double **red) {
+    const size_t r_bytes = align_up((size_t)v.N * v.C * vol_vox(v) * esize(dtype), 256);
+    const int rc = ensure_scratch(ctx, r_bytes + align_up((size_t)(kEnergyPartials + 8) * sizeof(double), 256));
+    if (rc != TNMF_OK) return rc;
+    if (R) *R = ws_at(ctx, 0);
+    if (red) *red = reinterpret_cast<double *>(ws_at(ctx, r_bytes));
+    return TNMF_OK;
+}
+
 int do_reconstruct(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *W, const void *H, void *R, hipStream_t s) {
     if (g.N == 0) return TNMF_OK;
     // the FFT family serves non-negative factorisations: outputs that are non-negative by construction are clamped
@@ -239,6 +295,84 @@ int do_corr_H(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const Scratch &sc, con
     return finalize_corr_H(g, dtype, partials, P, neg, pos, s);
 }
 
+
+// ---- three shift axes: the entry points below hand over to these (same argument meaning, C-contiguous H)
+int vol_api_reconstruct(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *W, const void *H, void *R, void *stream) {
+    VOL_ENTER(ctx, geom);
+    if (!W || (v.N > 0 && (!H || !R))) return TNMF_E_NULL;
+    return vol_reconstruct(v, dtype, W, H, R, s);
+}
+
+int vol_api_grad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *R_or_null, const void *W,
+                   const void *H, void *neg, void *pos, void *stream) {
+    VOL_ENTER(ctx, geom);
+    if (!W || (v.N > 0 && (!V || !neg || !pos))) return TNMF_E_NULL;
+    const void *R = R_or_null;
+    if (!R && v.N > 0) {
+        if (!H) return TNMF_E_NULL;
+        void *Rs;
+        CHECK(vol_scratch(ctx, v, dtype, &Rs, nullptr));
+        CHECK(vol_reconstruct(v, dtype, W, H, Rs, s));
+        R = Rs;
+    }
+    return vol_corr_W(v, dtype, V, R, W, nullptr, neg, pos, false, 0.0, s);
+}
+
+int vol_api_grad_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *R_scratch, int r_is_valid,
+                   const void *W, const void *H, void *neg, void *pos, void *stream) {
+    VOL_ENTER(ctx, geom);
+    if (!neg || !pos || (v.N > 0 && (!V || !H))) return TNMF_E_NULL;
+    const void *R = R_scratch;
+    if (v.N > 0 && !r_is_valid) {
+        if (!W) return TNMF_E_NULL;
+        void *Rs = const_cast<void *>(R_scratch);
+        if (!Rs) CHECK(vol_scratch(ctx, v, dtype, &Rs, nullptr));
+        CHECK(vol_reconstruct(v, dtype, W, H, Rs, s));
+        R = Rs;
+    }
+    return vol_corr_H(v, dtype, V, R, H, neg, pos, s);
+}
+
+int vol_api_energy(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,
+                   double *out_host, void *stream) {
+    VOL_ENTER(ctx, geom);
+    if (!out_host) return TNMF_E_NULL;
+    *out_host = 0.0;
+    if (v.N == 0) return TNMF_OK;
+    if (!V || !W || !H) return TNMF_E_NULL;
+    void *Rs;
+    double *red;
+    CHECK(vol_scratch(ctx, v, dtype, &Rs, &red));
+    CHECK(vol_reconstruct(v, dtype, W, H, Rs, s));
+    CHECK(launch_half_sqdiff(ctx, dtype, V, Rs, (size_t)v.N * v.C * vol_vox(v), red, red + kEnergyPartials, s));
+    TNMF_HIP_TRY(hipMemcpyAsync(out_host, red + kEnergyPartials, sizeof(double), hipMemcpyDeviceToHost, s));
+    TNMF_HIP_TRY(hipStreamSynchronize(s));
+    return TNMF_OK;
+}
+
+int vol_api_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, void *H_inout,
+                     void *R_scratch, int r_is_valid, double eps, double sparsity, void *stream) {
+    VOL_ENTER(ctx, geom);
+    if (v.N == 0) return TNMF_OK;
+    if (!V || !W || !H_inout) return TNMF_E_NULL;
+    void *Rs = R_scratch;
+    if (!Rs) {
+        if (r_is_valid) return TNMF_E_NULL;
+        CHECK(vol_scratch(ctx, v, dtype, &Rs, nullptr));
+    }
+    if (!r_is_valid) CHECK(vol_reconstruct(v, dtype, W, H_inout, Rs, s));
+    const double reg = eps + (sparsity > 0 ? sparsity : 0.0);   // TransformInvariantNMF.py:227-230
+    return vol_corr_W(v, dtype, V, Rs, W, H_inout, nullptr, nullptr, true, reg, s);
+}
+
+int vol_api_pad_fold(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, bool fold, const void *in, void *out,
+                     void *stream) {
+    VOL_ENTER(ctx, geom);
+    if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
+    if (v.N > 0 && (!in || !out)) return TNMF_E_NULL;
+    return vol_pad_fold(ctx, v, dtype, mode, fold, in, out, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -247,6 +381,13 @@ int tnmf_hip_abi_version(void) { return TNMF_HIP_ABI_VERSION; }
 
 int tnmf_hip_ctx_h_row_stride(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int *stride_out) {
     if (!ctx || !stride_out) return TNMF_E_NULL;
+    if (is_vol(geom)) {   // volumes: C-contiguous
+        Vol v;
+        const int vrc = to_vol(geom, &v);
+        if (vrc != TNMF_OK) return vrc;
+        *stride_out = v.H[2];
+        return TNMF_OK;
+    }
     Geo g;
     const int rc = to_geo(geom, &g);
     if (rc != TNMF_OK) return rc;
@@ -330,6 +471,11 @@ int tnmf_hip_ctx_destroy(tnmf_hip_ctx *ctx) {
 
 int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom) {
     void *stream = nullptr;
+    if (is_vol(geom)) {
+        VOL_ENTER(ctx, geom);
+        (void)s;
+        return vol_scratch(ctx, v, dtype, nullptr, nullptr);
+    }
     ENTER(ctx, geom);
     (void)s;
     if (g.N > 0 && ctx->path == TNMF_PATH_FFT) CHECK(fft_reserve(ctx, g, dtype, true));
@@ -363,6 +509,10 @@ int tnmf_hip_ctx_set_cache(tnmf_hip_ctx *ctx, int enable) {
 int tnmf_hip_ctx_bind(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *H, const void *V) {
     if (!ctx) return TNMF_E_NULL;
     if (!geom || !H) {
+        fft_unbind(ctx);
+        return TNMF_OK;
+    }
+    if (is_vol(geom)) {   // (the spectrum cache belongs to the FFT family: nothing to bind for volumes)
         fft_unbind(ctx);
         return TNMF_OK;
     }
@@ -401,6 +551,7 @@ int tnmf_hip_diag_set_ablate(tnmf_hip_ctx *ctx, int mask) {
 
 int tnmf_hip_reconstruct(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *W, const void *H, void *R,
                          void *stream) {
+    if (is_vol(geom)) return vol_api_reconstruct(ctx, geom, W, H, R, stream);
     ENTER(ctx, geom);
     if (!W || (g.N > 0 && (!H || !R))) return TNMF_E_NULL;
     return do_reconstruct(ctx, g, dtype, W, H, R, s);
@@ -408,6 +559,7 @@ int tnmf_hip_reconstruct(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const voi
 
 int tnmf_hip_grad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *R_or_null,
                     const void *W, const void *H, void *neg, void *pos, void *stream) {
+    if (is_vol(geom)) return vol_api_grad_H(ctx, geom, V, R_or_null, W, H, neg, pos, stream);
     ENTER(ctx, geom);
     if (!W || (g.N > 0 && (!V || !neg || !pos))) return TNMF_E_NULL;
     const void *R = R_or_null;
@@ -424,6 +576,7 @@ int tnmf_hip_grad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V,
 
 int tnmf_hip_grad_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *R_or_null,
                     const void *W, const void *H, void *neg, void *pos, void *stream) {
+    if (is_vol(geom)) return vol_api_grad_W(ctx, geom, V, R_or_null, R_or_null != nullptr, W, H, neg, pos, stream);
     ENTER(ctx, geom);
     if (!neg || !pos || (g.N > 0 && (!V || !H))) return TNMF_E_NULL;
     const Scratch sc = plan_scratch(ctx, g, dtype);
@@ -449,6 +602,11 @@ int tnmf_hip_mu_update(tnmf_hip_ctx *ctx, int dtype, void *arr, const void *neg,
 }
 
 int tnmf_hip_normalize_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W, void *stream) {
+    if (is_vol(geom)) {
+        VOL_ENTER(ctx, geom);
+        if (!W) return TNMF_E_NULL;
+        return launch_apply_normalize_W(vol_dict_geo(v), dtype, W, nullptr, nullptr, 0.0, false, s);
+    }
     ENTER(ctx, geom);
     if (!W) return TNMF_E_NULL;
     fft_invalidate_W(ctx);
@@ -457,6 +615,7 @@ int tnmf_hip_normalize_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W, 
 
 int tnmf_hip_energy(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,
                     double *out_host, void *stream) {
+    if (is_vol(geom)) return vol_api_energy(ctx, geom, V, W, H, out_host, stream);
     ENTER(ctx, geom);
     if (!out_host) return TNMF_E_NULL;
     if (g.N == 0) {
@@ -492,7 +651,19 @@ int tnmf_hip_convolve_multi_1d(tnmf_hip_ctx *ctx, int dtype, int ndim, size_t ro
     return launch_convolve_axis(ctx, dtype, tmp, out, rows * (size_t)shape[0], shape[1], 1, kernel1, len1, s);
 }
 
+int tnmf_hip_convolve_axis(tnmf_hip_ctx *ctx, int dtype, size_t rows, int len, size_t inner, const void *in, void *out,
+                           const double *kernel, int klen, void *stream) {
+    if (!ctx || !kernel) return TNMF_E_NULL;
+    if (dtype != 0 && dtype != 1) return TNMF_E_DTYPE;
+    if (len < 0 || inner > 0x7fffffffu) return TNMF_E_GEOM;
+    TNMF_HIP_TRY(hipSetDevice(ctx->device));
+    if (rows == 0 || len == 0 || inner == 0) return TNMF_OK;
+    if (!in || !out || in == out) return TNMF_E_NULL;
+    return launch_convolve_axis(ctx, dtype, in, out, rows, len, (int)inner, kernel, klen, static_cast<hipStream_t>(stream));
+}
+
 int tnmf_hip_pad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *H, void *Hpad, void *stream) {
+    if (is_vol(geom)) return vol_api_pad_fold(ctx, geom, mode, false, H, Hpad, stream);
     ENTER(ctx, geom);
     if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
     if (g.N > 0 && (!H || !Hpad)) return TNMF_E_NULL;
@@ -501,6 +672,7 @@ int tnmf_hip_pad_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const
 }
 
 int tnmf_hip_fold_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *Gpad, void *G, void *stream) {
+    if (is_vol(geom)) return vol_api_pad_fold(ctx, geom, mode, true, Gpad, G, stream);
     ENTER(ctx, geom);
     if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
     if (g.N > 0 && (!Gpad || !G)) return TNMF_E_NULL;
@@ -509,6 +681,7 @@ int tnmf_hip_fold_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, cons
 
 int tnmf_hip_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, void *H_inout,
                       void *R_scratch, int r_is_valid, double eps, double sparsity, void *stream) {
+    if (is_vol(geom)) return vol_api_update_H(ctx, geom, V, W, H_inout, R_scratch, r_is_valid, eps, sparsity, stream);
     ENTER(ctx, geom);
     if (g.N == 0) return TNMF_OK;
     if (!V || !W || !H_inout) return TNMF_E_NULL;
@@ -529,6 +702,8 @@ int tnmf_hip_update_H_ex(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode,
                          void *H_inout, void *R_scratch, double eps, double sparsity, double inhibition,
                          double cross_inhibition, const double *kernel0, int len0, const double *kernel1, int len1,
                          void *stream) {
+    // (volumes: the caller composes the half step from the primitives, tnmf_hip_convolve_axis and tnmf_hip_mu_update)
+    if (is_vol(geom)) return ctx ? TNMF_E_UNSUPPORTED : TNMF_E_NULL;
     ENTER(ctx, geom);
     if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
     if (g.N == 0) return TNMF_OK;
@@ -599,6 +774,14 @@ int tnmf_hip_update_H_ex(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode,
 
 int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,
                           void *R_scratch, int r_is_valid, void *negpos, void *stream) {
+    if (is_vol(geom)) {
+        if (!negpos || (r_is_valid && !R_scratch)) return TNMF_E_NULL;
+        Vol vv;
+        CHECK(to_vol(geom, &vv));
+        char *np3 = static_cast<char *>(negpos);
+        return vol_api_grad_W(ctx, geom, V, R_scratch, r_is_valid, W, H, np3,
+                              np3 + (size_t)vv.M * vv.C * vol_avox(vv) * esize(geom->dtype), stream);
+    }
     ENTER(ctx, geom);
     if (!negpos || !W || (g.N > 0 && (!V || !H))) return TNMF_E_NULL;
     const Scratch sc = plan_scratch(ctx, g, dtype);
@@ -614,6 +797,7 @@ int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
 int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, void *W_inout, void *H_inout,
                           void *R_scratch, void *acc, const tnmf_hip_op *ops, int n_ops, double eps, double sparsity,
                           void *stream) {
+    if (is_vol(geom)) return ctx ? TNMF_E_UNSUPPORTED : TNMF_E_NULL;   // (volumes: step by step through the primitives)
     ENTER(ctx, geom);
     if (n_ops < 0 || (n_ops > 0 && !ops)) return TNMF_E_NULL;
     if (!V || !W_inout || !H_inout || !acc) return TNMF_E_NULL;
@@ -746,6 +930,13 @@ int tnmf_hip_sum_parts(tnmf_hip_ctx *ctx, int dtype, const void *parts, int n_pa
 
 int tnmf_hip_apply_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, void *W_inout, void *negpos, double eps,
                      void *stream) {
+    if (is_vol(geom)) {
+        VOL_ENTER(ctx, geom);
+        if (!W_inout || !negpos) return TNMF_E_NULL;
+        char *np3 = static_cast<char *>(negpos);
+        return launch_apply_normalize_W(vol_dict_geo(v), dtype, W_inout, np3,
+                                        np3 + (size_t)v.M * v.C * vol_avox(v) * esize(dtype), eps, true, s);
+    }
     ENTER(ctx, geom);
     if (!W_inout || !negpos) return TNMF_E_NULL;
     fft_invalidate_W(ctx);

@@ -495,6 +495,9 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
             };
             load_b(0, 0);
             load_a(0, 0);
+            // the wave inside its MFMA loop outranks its SIMD partner, which is in its epilogue most of that time (VALU issue is
+            // arbitrated by priority, then age; measured 1.725 -> 1.713 ms at config 3, the opposite assignment 1.74)
+            __builtin_amdgcn_s_setprio(1);
             static_for<G>([&](auto gic) {
                 constexpr int gi = decltype(gic)::value;
                 constexpr int kb = gi >> 2, rb = (gi >> 1) & 1, x = gi & 1;
@@ -529,6 +532,7 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
                 // instantiation; two plain scheduling fences per group give the same instruction stream.)
                 __builtin_amdgcn_sched_barrier(0);
             });
+            __builtin_amdgcn_s_setprio(0);
             // short loops (the 1-D instantiations with few taps: fewer than 12 groups): the memory slots the loop had no
             // group for are issued behind it
             static_for<12>([&](auto kc) {

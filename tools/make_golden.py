@@ -28,6 +28,7 @@ import numpy as np
 REF = '/root/reference'
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
 FACE_DAT = '/opt/conda/lib/python3.9/site-packages/scipy/misc/face.dat'
+ONLY = ''
 
 
 def reference_backend():
@@ -51,8 +52,13 @@ def make_primitives():
         '2d_c3': (2, 3, (20, 27), 4, (5, 7), None),
         '2d_slice': (5, 2, (13, 19), 3, (3, 6), (1, 4)),
         '2d_wide': (2, 1, (6, 37), 33, (2, 12), None),
+        # three shift axes (volumes): the reference backend dispatches conv3d (backends/PyTorch.py:13-17)
+        '3d_c1': (2, 1, (7, 9, 11), 3, (2, 3, 4), None),
+        '3d_c2_slice': (3, 2, (6, 8, 10), 4, (3, 2, 3), (1, 3)),
     }
     for name, (N, C, D, M, A, sl) in cases.items():
+        if ONLY and ONLY not in name:
+            continue
         k = len(A)
         gen = np.random.default_rng(sum(map(ord, name)))
         V = gen.random((N, C) + D)
@@ -86,9 +92,12 @@ def make_mode_primitives():
     """Same outputs for the non-'valid' reconstruction modes (padding table: backends/_PyTorchBackend.py:42-52)."""
     import torch
     Backend = reference_backend()
-    cases = {'1d': (3, 2, (17,), 3, (5,), (1, 3)), '2d': (2, 2, (13, 16), 3, (4, 5), None)}
+    cases = {'1d': (3, 2, (17,), 3, (5,), (1, 3)), '2d': (2, 2, (13, 16), 3, (4, 5), None),
+             '3d': (2, 2, (7, 8, 9), 3, (3, 2, 4), None)}
     for mode in ('full', 'circular', 'reflect'):
         for name, (N, C, D, M, A, sl) in cases.items():
+            if ONLY and ONLY not in name:
+                continue
             k = len(A)
             gen = np.random.default_rng(sum(map(ord, mode + name)))
             V = gen.random((N, C) + D)
@@ -138,8 +147,11 @@ def make_racoon():
 
 
 if __name__ == '__main__':
+    # optional argument: only the cases whose name contains it (e.g. `3d`; the image fixtures are skipped then)
+    ONLY = sys.argv[1] if len(sys.argv) > 1 else ''
     os.makedirs(OUT, exist_ok=True)
     make_primitives()
     make_mode_primitives()
-    make_racoon()
+    if not ONLY:
+        make_racoon()
     print('written to', OUT)

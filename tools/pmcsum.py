@@ -15,3 +15,11 @@ for k, cs in agg.items():
     print(k)
     for c, v in sorted(cs.items()):
         print(f'   {c:45s} n={len(v):3d}  avg={sum(v) / len(v):.4g}')
+# durations of the same dispatches (kernel trace written beside the counters): average ns per kernel
+dur = collections.defaultdict(list)
+for f in glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if pat in r['Kernel_Name']:
+            dur[r['Kernel_Name'][:60]].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+for k, v in dur.items():
+    print(f'{k}   avg duration {sum(v) / len(v) / 1e3:.1f} us over {len(v)} dispatches')
