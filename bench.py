@@ -72,6 +72,9 @@ CONFIGS = {
     # not a BASELINE config: the geometry of the reference's mini-batch tests (tnmf/tests/test_minibatch.py:35-73: 768
     # patches 1 x 32 x 32, 10 atoms 7 x 7, batch_size 3) -- small-batch stochastic schedules are launch-latency bound
     8: dict(N=768, C=1, D=(32, 32), M=10, A=(7, 7)),
+    # not a BASELINE config: volumes (three shift axes; the reference's PyTorch backend takes them through conv3d,
+    # tnmf/backends/PyTorch.py:13-17) -- the direct kernels of tnmf_amd/csrc/volume.hip
+    9: dict(N=16, C=1, D=(64, 64, 64), M=8, A=(5, 5, 5)),
 }
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector = f32 MFMA
 PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
@@ -115,12 +118,15 @@ def synth_V_on_device(cfg, n_local, seed, device):
 # kernel group of the timeline -> kernel family -> (name of its main kernel as rocprof prints it, further kernels)
 GROUP_KERNELS = {
     'update_H': {'split': ('k_split_corr_W', ()), 'mfma': ('k_mfma_corr_W', ()), 'generic': ('k_corr_W', ()),
+                 'volume': ('k_vol_corr_W', ()),
                  'fft': ('k_fft_rows_mu', ('k_fft_grad_H', 'k_fft_rows_fwd', 'k_fft_cols_fwd'))},
     'reconstruct': {'fft': ('k_mix_reconstruct', ('k_fft_rows_fwd', 'k_fft_rows_inv', 'k_fft_contract_R',
                                                    'k_spectral_contract_R', 'k_fft_cols_fwd', 'k_fft_cols_inv')),
-                    'mfma': ('k_mfma_reconstruct', ()), 'generic': ('k_reconstruct', ())},
+                    'mfma': ('k_mfma_reconstruct', ()), 'generic': ('k_reconstruct', ()),
+                    'volume': ('k_vol_reconstruct', ())},
     'grad_W': {'fft': ('k_mix_grad_W', ('k_fft_grad_W', 'k_spectral_grad_W', 'k_fft_sum_groups', 'k_fft_rows_fwd')),
-               'mfma': ('k_mfma_corr_H', ('k_corr_H_finalize',)), 'generic': ('k_corr_H', ('k_corr_H_finalize',))},
+               'mfma': ('k_mfma_corr_H', ('k_corr_H_finalize',)), 'generic': ('k_corr_H', ('k_corr_H_finalize',)),
+               'volume': ('k_vol_corr_H', ())},
 }
 
 

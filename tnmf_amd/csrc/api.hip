@@ -200,13 +200,19 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
     TNMF_HIP_TRY(hipSetDevice((ctx)->device));             \
     (ctx)->last_path = "volume";
 
-// scratch of a volume call: [R of the slice | energy partials + result]
-int vol_scratch(tnmf_hip_ctx *ctx, const Vol &v, int dtype, void **R, double **red) {
+// scratch of a volume call: [R of the slice | energy partials + result | partial sums of the W gradient]
+int vol_scratch(tnmf_hip_ctx *ctx, const Vol &v, int dtype, void **R, double **red, double **part = nullptr,
+                int *P = nullptr) {
     const size_t r_bytes = align_up((size_t)v.N * v.C * vol_vox(v) * esize(dtype), 256);
-    const int rc = ensure_scratch(ctx, r_bytes + align_up((size_t)(kEnergyPartials + 8) * sizeof(double), 256));
+    const size_t e_bytes = align_up((size_t)(kEnergyPartials + 8) * sizeof(double), 256);
+    const int chunks = vol_corr_H_chunks(ctx, v);
+    const size_t p_bytes = align_up((size_t)chunks * v.M * v.C * vol_avox(v) * 2 * sizeof(double), 256);
+    const int rc = ensure_scratch(ctx, r_bytes + e_bytes + p_bytes);
     if (rc != TNMF_OK) return rc;
     if (R) *R = ws_at(ctx, 0);
     if (red) *red = reinterpret_cast<double *>(ws_at(ctx, r_bytes));
+    if (part) *part = reinterpret_cast<double *>(ws_at(ctx, r_bytes + e_bytes));
+    if (P) *P = chunks;
     return TNMF_OK;
 }
 
@@ -323,14 +329,17 @@ int vol_api_grad_W(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, 
     VOL_ENTER(ctx, geom);
     if (!neg || !pos || (v.N > 0 && (!V || !H))) return TNMF_E_NULL;
     const void *R = R_scratch;
+    void *Rws;
+    double *part;
+    int P;
+    CHECK(vol_scratch(ctx, v, dtype, &Rws, nullptr, &part, &P));
     if (v.N > 0 && !r_is_valid) {
         if (!W) return TNMF_E_NULL;
-        void *Rs = const_cast<void *>(R_scratch);
-        if (!Rs) CHECK(vol_scratch(ctx, v, dtype, &Rs, nullptr));
+        void *Rs = R_scratch ? const_cast<void *>(R_scratch) : Rws;
         CHECK(vol_reconstruct(v, dtype, W, H, Rs, s));
         R = Rs;
     }
-    return vol_corr_H(v, dtype, V, R, H, neg, pos, s);
+    return vol_corr_H(v, dtype, V, R, H, neg, pos, part, P, s);
 }
 
 int vol_api_energy(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, const void *W, const void *H,

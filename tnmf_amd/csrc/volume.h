@@ -14,6 +14,9 @@ int vol_reconstruct(const Vol &v, int dtype, const void *W, const void *H, void 
 // fused: H <- H * neg / (pos + reg) in place; otherwise neg / pos (shaped like H) are written
 int vol_corr_W(const Vol &v, int dtype, const void *V, const void *R, const void *W, void *Hio, void *neg, void *pos,
                bool fused, double reg, hipStream_t s);
-int vol_corr_H(const Vol &v, int dtype, const void *V, const void *R, const void *H, void *neg, void *pos, hipStream_t s);
+// partials: P * M * C * |A| * 2 doubles of scratch (P = vol_corr_H_chunks)
+int vol_corr_H_chunks(const tnmf_hip_ctx *ctx, const Vol &v);
+int vol_corr_H(const Vol &v, int dtype, const void *V, const void *R, const void *H, void *neg, void *pos,
+               double *partials, int P, hipStream_t s);
 int vol_pad_fold(const tnmf_hip_ctx *ctx, const Vol &v, int dtype, int mode, bool fold, const void *in, void *out,
                  hipStream_t s);

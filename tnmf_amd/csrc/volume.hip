@@ -82,47 +82,84 @@ __global__ __launch_bounds__(kVolBlock) void k_vol_corr_W(Vol v, int tiles, cons
     }
 }
 
-// one workgroup per dictionary entry (m, c, a): rows (n, z, y) dealt to the four waves, x along the lanes; double sums,
-// reduced lane by lane and wave by wave in a fixed order
+// W gradient.  A workgroup owns one (atom, channel, az, ay) and a chunk p of the rows (n, z, y) of the samples; its waves
+// take rows in turn, the lanes run along x, and every thread keeps the sums of up to kVolTaps taps ax -- one load of V and
+// R per voxel serves all of them.  Sums are doubles; lanes, waves (and, in k_vol_corr_H_finalize, chunks) are added up
+// in a fixed order: bit-reproducible.  partials[p][(m, c, a)][neg | pos].
+constexpr int kVolTaps = 8;
+
 template <typename T>
-__global__ __launch_bounds__(kVolBlock) void k_vol_corr_H(Vol v, const T *__restrict__ V, const T *__restrict__ Rr,
-                                                          const T *__restrict__ H, T *__restrict__ neg,
-                                                          T *__restrict__ pos) {
-    const int avox = v.A[0] * v.A[1] * v.A[2];
-    const int a = blockIdx.x % avox, mc = blockIdx.x / avox;
+__global__ __launch_bounds__(kVolBlock) void k_vol_corr_H(Vol v, int P, const T *__restrict__ V, const T *__restrict__ Rr,
+                                                          const T *__restrict__ H, double *__restrict__ partials) {
+    const int avox = v.A[0] * v.A[1] * v.A[2], nzy = v.A[0] * v.A[1];
+    const int p = blockIdx.x % P, e = blockIdx.x / P;
+    const int azy = e % nzy, mc = e / nzy;
     const int c = mc % v.C, m = mc / v.C;
-    const int ax = a % v.A[2], ay = (a / v.A[2]) % v.A[1], az = a / (v.A[2] * v.A[1]);
-    const int oz = v.A[0] - 1 - az, oy = v.A[1] - 1 - ay, ox = v.A[2] - 1 - ax;
+    const int ay = azy % v.A[1], az = azy / v.A[1];
+    const int oz = v.A[0] - 1 - az, oy = v.A[1] - 1 - ay;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rows = (long)v.N * v.D[0] * v.D[1];
-    double sn = 0, sp = 0;
-    for (long r = wave; r < rows; r += kVolBlock / 64) {
-        const int y = (int)(r % v.D[1]);
-        const long rest = r / v.D[1];
-        const int z = (int)(rest % v.D[0]), n = (int)(rest / v.D[0]);
-        const size_t xo = ((((size_t)n * v.C + c) * v.D[0] + z) * v.D[1] + y) * v.D[2];
-        const T *hrow = H + ((((size_t)n * v.M + m) * v.H[0] + z + oz) * v.H[1] + y + oy) * v.H[2] + ox;
-        for (int x = lane; x < v.D[2]; x += 64) {
-            const double h = (double)hrow[x];
-            sn += h * (double)V[xo + x];
-            sp += h * (double)Rr[xo + x];
+    const long r0 = rows * p / P, r1 = rows * (p + 1) / P;
+    __shared__ double red[kVolBlock / 64][2 * kVolTaps];
+    for (int a0 = 0; a0 < v.A[2]; a0 += kVolTaps) {
+        double sn[kVolTaps], sp[kVolTaps];
+#pragma unroll
+        for (int t = 0; t < kVolTaps; ++t) sn[t] = sp[t] = 0;
+        const int nt = v.A[2] - a0 < kVolTaps ? v.A[2] - a0 : kVolTaps;
+        for (long r = r0 + wave; r < r1; r += kVolBlock / 64) {
+            const int y = (int)(r % v.D[1]);
+            const long rest = r / v.D[1];
+            const int z = (int)(rest % v.D[0]), n = (int)(rest / v.D[0]);
+            const size_t xo = ((((size_t)n * v.C + c) * v.D[0] + z) * v.D[1] + y) * v.D[2];
+            // tap ax reads H at x + A[2]-1 - ax
+            const T *hrow = H + ((((size_t)n * v.M + m) * v.H[0] + z + oz) * v.H[1] + y + oy) * v.H[2] + v.A[2] - 1 - a0;
+            for (int x = lane; x < v.D[2]; x += 64) {
+                const double vv = (double)V[xo + x], rr = (double)Rr[xo + x];
+#pragma unroll
+                for (int t = 0; t < kVolTaps; ++t)
+                    if (t < nt) {
+                        const double h = (double)hrow[x - t];
+                        sn[t] += h * vv;
+                        sp[t] += h * rr;
+                    }
+            }
         }
-    }
-    __shared__ double red[2][kVolBlock];
-    red[0][threadIdx.x] = sn;
-    red[1][threadIdx.x] = sp;
-    __syncthreads();
-    for (int w = kVolBlock / 2; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + w];
-            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+#pragma unroll
+        for (int t = 0; t < kVolTaps; ++t) {
+#pragma unroll
+            for (int w = 32; w > 0; w >>= 1) {
+                sn[t] += __shfl_down(sn[t], w);
+                sp[t] += __shfl_down(sp[t], w);
+            }
+            if (lane == 0) {
+                red[wave][2 * t] = sn[t];
+                red[wave][2 * t + 1] = sp[t];
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * nt) {
+            double acc = red[0][threadIdx.x];
+            for (int w = 1; w < kVolBlock / 64; ++w) acc += red[w][threadIdx.x];
+            const int t = threadIdx.x >> 1;
+            const size_t o = ((size_t)mc * nzy + azy) * v.A[2] + a0 + t;
+            partials[((size_t)p * v.M * v.C * avox + o) * 2 + (threadIdx.x & 1)] = acc;
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        neg[blockIdx.x] = (T)red[0][0];
-        pos[blockIdx.x] = (T)red[1][0];
+}
+
+template <typename T>
+__global__ void k_vol_corr_H_finalize(int n, int P, const double *__restrict__ partials, T *__restrict__ neg,
+                                      T *__restrict__ pos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0, b = 0;
+    for (int p = 0; p < P; ++p) {
+        a += partials[((size_t)p * n + i) * 2];
+        b += partials[((size_t)p * n + i) * 2 + 1];
     }
+    neg[i] = (T)a;
+    pos[i] = (T)b;
 }
 
 // ---- reconstruction modes (backends/_PyTorchBackend.py:42-52): the same per-axis maps as the 1-D / 2-D kernels of
@@ -230,15 +267,33 @@ int vol_corr_W(const Vol &v, int dtype, const void *V, const void *R, const void
     return TNMF_OK;
 }
 
-int vol_corr_H(const Vol &v, int dtype, const void *V, const void *R, const void *H, void *neg, void *pos, hipStream_t s) {
+int vol_corr_H_chunks(const tnmf_hip_ctx *ctx, const Vol &v) {
+    // enough workgroups for four per CU, no chunk below eight rows
+    const long entries = (long)v.M * v.C * v.A[0] * v.A[1], rows = (long)v.N * v.D[0] * v.D[1];
+    long P = (4L * ctx->num_cu + entries - 1) / entries;
+    if (P > rows / 8) P = rows / 8;
+    if (P > 1024) P = 1024;
+    return P < 1 ? 1 : (int)P;
+}
+
+int vol_corr_H(const Vol &v, int dtype, const void *V, const void *R, const void *H, void *neg, void *pos,
+               double *partials, int P, hipStream_t s) {
     if (!vol_fits(v)) return TNMF_E_GEOM;
-    const dim3 grid((unsigned)(v.M * v.C * v.A[0] * v.A[1] * v.A[2]));   // (an empty slice: every sum is zero)
-    if (dtype == 0)
-        hipLaunchKernelGGL(k_vol_corr_H<float>, grid, dim3(kVolBlock), 0, s, v, (const float *)V, (const float *)R,
-                           (const float *)H, (float *)neg, (float *)pos);
-    else
-        hipLaunchKernelGGL(k_vol_corr_H<double>, grid, dim3(kVolBlock), 0, s, v, (const double *)V, (const double *)R,
-                           (const double *)H, (double *)neg, (double *)pos);
+    const long entries = (long)v.M * v.C * v.A[0] * v.A[1];
+    if (entries * P > 0x7fffffffL) return TNMF_E_GEOM;
+    const dim3 grid((unsigned)(entries * P));   // (an empty slice: every sum is zero)
+    const int n = v.M * v.C * v.A[0] * v.A[1] * v.A[2];
+    if (dtype == 0) {
+        hipLaunchKernelGGL(k_vol_corr_H<float>, grid, dim3(kVolBlock), 0, s, v, P, (const float *)V, (const float *)R,
+                           (const float *)H, partials);
+        hipLaunchKernelGGL(k_vol_corr_H_finalize<float>, dim3(cdiv(n, kVolBlock)), dim3(kVolBlock), 0, s, n, P, partials,
+                           (float *)neg, (float *)pos);
+    } else {
+        hipLaunchKernelGGL(k_vol_corr_H<double>, grid, dim3(kVolBlock), 0, s, v, P, (const double *)V, (const double *)R,
+                           (const double *)H, partials);
+        hipLaunchKernelGGL(k_vol_corr_H_finalize<double>, dim3(cdiv(n, kVolBlock)), dim3(kVolBlock), 0, s, n, P, partials,
+                           (double *)neg, (double *)pos);
+    }
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
 }
