@@ -780,5 +780,5 @@ def test_errors_like_the_reference():
     be = HIP_Backend()
     with pytest.raises(TypeError):
         be.initialize(np.ones((1, 1, 8), dtype=np.int32), (3,), 2, None, (-1,))
-    with pytest.raises(NotImplementedError):
-        be.initialize(np.ones((1, 1, 4, 4, 4)), (2, 2, 2), 2, None, (-3, -2, -1))
+    with pytest.raises(NotImplementedError):                         # four shift axes (the reference's PyTorch backend
+        be.initialize(np.ones((1, 1, 4, 4, 4, 4)), (2, 2, 2, 2), 2, None, (-4, -3, -2, -1))   # asserts k <= 3: PyTorch.py:32)

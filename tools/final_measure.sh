@@ -24,6 +24,7 @@ if [ "$3" != "nobench" ]; then
   timeout -k 10 300 python3 bench.py --config 1 $Q --steps 200 --warmup 20 > $out/bench_config1.json 2> $out/b.err || exit 1
   timeout -k 10 300 python3 bench.py --config 1 $Q --steps 200 --warmup 20 --eager > $out/bench_config1_eager.json 2> $out/b.err || exit 1
   timeout -k 10 300 python3 bench.py --config 7 $Q --steps 20 --warmup 3 > $out/bench_long_1d.json 2> $out/b.err || exit 1
+  timeout -k 10 300 python3 bench.py --config 9 $Q --steps 10 --warmup 2 > $out/bench_volumes.json 2> $out/b.err || exit 1
   for a in asg asag cyclic gsg gsag; do
     timeout -k 10 300 python3 bench.py --config 8 --batch-size 3 $Q --steps 5 --warmup 2 --algorithm $a > $out/bench_minibatch_geometry_$a.json 2> $out/b.err || exit 1
     timeout -k 10 300 python3 bench.py --config 8 --batch-size 3 $Q --steps 5 --warmup 2 --algorithm $a --eager > $out/bench_minibatch_geometry_${a}_eager.json 2> $out/b.err || exit 1
