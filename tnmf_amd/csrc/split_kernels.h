@@ -242,19 +242,32 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
         }
     }
 
-    // Work assignment: a workgroup takes whole row blocks (8 rows x the full width of the shift plane of one sample) and
-    // walks their column tiles left to right.  Rows of H are Hx floats long -- not a multiple of the 128-byte cache line --
+    // Work assignment: a workgroup walks row blocks (8 rows x the full width of the shift plane of one sample) column tile
+    // by column tile, left to right.  Rows of H are Hx floats long -- not a multiple of the 128-byte cache line --
     // so every 32-pixel tile shares its first and last line of each row with its neighbours: walked by ONE workgroup the
     // shared lines are read and written within one L2 (the row block of a plane is one contiguous 8.5 KB region);
     // dealt to different workgroups they were fetched twice and written back as partial lines from two XCDs (measured
     // 1.7x the algorithmic H traffic).
     // (1-D: tiles_y = row blocks of eight SAMPLES; n stays 0 and u0 is the first sample of the block)
+    // Row blocks are dealt round robin (workgroup b takes b, b + P, ...) as long as every workgroup gets one; the row
+    // blocks left over are dealt TILE by tile -- whole blocks would leave some workgroups a block ahead of the others:
+    // at BASELINE config 2 (1088 row blocks of five tiles on 512 workgroups) three rounds where 2.1 do (0.131 -> 0.117 ms).
+    // (Contiguous runs of tiles per workgroup balance as well, and measured 0.5 % slower at config 3.)
     const int nblocks = ONE_D ? tiles_y : g.N * tiles_y;   // row blocks
+    const int P = gridDim.x, full = nblocks / P;           // whole rounds of row blocks
+    const int left = (nblocks - full * P) * tiles_x;       // tiles of the last, partial round
     auto stage_coords = [&](int st, int &n, int &u0, int &v0, int &c) {
         c = st % g.C;
         const int tl = st / g.C;                                   // tile index within this workgroup's walk
-        const int txi = tl % tiles_x;
-        const int rbk = blockIdx.x + (tl / tiles_x) * gridDim.x;   // row block
+        int txi, rbk;
+        if (tl < full * tiles_x) {
+            txi = tl % tiles_x;
+            rbk = blockIdx.x + (tl / tiles_x) * P;                 // row block
+        } else {
+            const int t = blockIdx.x + (tl - full * tiles_x) * P;  // tile of the partial round
+            txi = t % tiles_x;
+            rbk = full * P + t / tiles_x;
+        }
         const int tyi = rbk % tiles_y;
         n = ONE_D ? 0 : rbk / tiles_y;
         u0 = tyi * SP_TY;
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(kBlock, 2) TNMF_NO_DS_PAIRING void k_split_corr_W(G
         }
     };
 
-    const int my_tiles = (blockIdx.x < nblocks ? (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0) * tiles_x;
+    const int my_tiles = full * tiles_x + ((int)blockIdx.x < left ? (left - blockIdx.x + P - 1) / P : 0);
     const int my_stages = my_tiles * g.C;
     if (my_stages > 0) {
         prefetch_setup(0);
@@ -713,7 +726,7 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
     const int per_cu = Cfg::lds <= 80 * 1024 ? 2 : 1;
     long P = ((long)per_cu * ctx->num_cu) / MT;
     if (P < 1) P = 1;
-    if (P > nrowblocks) P = nrowblocks;   // a workgroup walks whole row blocks
+    if (P > ntiles) P = ntiles;   // (row blocks round robin, the last partial round tile by tile)
     const dim3 grid((unsigned)P, MT);
     unsigned long long *dbg = nullptr;
     const size_t nw = (size_t)P * MT * 4;
