@@ -43,7 +43,7 @@ def planted_V(N, C, D, M, A, seed, dtype=np.float32, density=0.01):
     for lo in range(0, N, 32):          # bounded temporaries
         n = min(32, N - lo)
         Ht = rng.random((n, M) + Hs) * (rng.random((n, M) + Hs) < density)
-        V[lo:lo + n] = orc.reconstruct(Wt, Ht, 'c') + 0.01 * rng.random((n, C) + D)
+        V[lo:lo + n] = orc.reconstruct(Wt, Ht, 'c' if len(A) < 3 else 'contract') + 0.01 * rng.random((n, C) + D)
     return V
 
 
@@ -178,7 +178,8 @@ def _fit(V, M, A, mode, pg=None, **kw):
 @pytest.mark.parametrize('dtype,geom,tol', [
     (np.float64, (2, (20, 24), 5, (4, 5)), 1e-10),
     (np.float32, (1, (96, 80), 32, (12, 12)), 1e-5),      # large enough for the hybrid dispatch on every rank
-], ids=['f64', 'f32_hybrid'])
+    (np.float64, (1, (6, 7, 9), 3, (2, 3, 3)), 1e-10),    # three shift axes: the volume kernels behind the same sharding
+], ids=['f64', 'f32_hybrid', 'f64_volume'])
 def test_two_ranks_in_one_process(mode, dtype, geom, tol):
     """HIP_Backend's world > 1 branch: shard bounds, local slices, empty tail batches, the [neg|pos] all-reduce, the
     energy all-reduce.  N = 7 over 2 ranks is an uneven split (4 + 3); Cyclic-MU with batch_size 2 gives every rank
@@ -210,7 +211,7 @@ def test_two_ranks_in_one_process(mode, dtype, geom, tol):
     single = _fit(V, M, A, mode)
     H2 = np.concatenate([r0['H'], r1['H']])
     np.random.seed(42)
-    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c')
+    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c' if len(A) < 3 else 'contract')
     if mode == 'batch':
         ref.fit(V.astype(np.float64), n_iterations=3, sparsity_H=0.05)
     else:
