@@ -170,8 +170,8 @@ int tnmf_hip_convolve_axis(tnmf_hip_ctx *ctx, int dtype, size_t rows, int len, s
  * one to three in PyTorch (tnmf/backends/PyTorch.py:13-17: conv1d / conv2d / conv3d).  With ndim == 3 the entry points
  * tnmf_hip_reconstruct, _grad_H, _grad_W, _grad_W_fused, _update_H, _apply_W, _normalize_W, _energy, _pad_H, _fold_H and
  * _ctx_reserve run direct kernels of their own (float32 and float64, C-contiguous activations: h_row_stride 0 or the
- * shift width); _mu_update, _axpby, _sum_parts and _convolve_axis do not look at the geometry.  tnmf_hip_update_H_ex and
- * tnmf_hip_run_schedule answer TNMF_E_UNSUPPORTED (the caller composes those steps from the entry points above);
+ * shift width), and so does tnmf_hip_update_H_ex; _mu_update, _axpby, _sum_parts and _convolve_axis do not look at the
+ * geometry.  tnmf_hip_run_schedule answers TNMF_E_UNSUPPORTED (the caller drives the schedules step by step);
  * tnmf_hip_ctx_bind is accepted and has nothing to do.  tnmf_hip_ctx_last_path reads "volume". */
 
 /* ---- reconstruction modes other than 'valid' --------------------------------------------------------------------
@@ -200,16 +200,17 @@ int tnmf_hip_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *
  *   G   = kernel0 (*) kernel1 (*) H  along the shift axes, zeros outside (Backend.convolve_multi_1d, _NumPyBackend.py:56-64)
  *   pos += inhibition * (G - H) + cross_inhibition / (M - 1) * (sum over atoms of G - G)            (:256-269)
  *   H  *= neg / (pos + eps + sparsity)
- * kernel0 / kernel1: HOST pointers to the odd-length 1-D kernels of the shift axes (ndim == 1: kernel0 only), ignored when
- * both strengths are 0.  mode == TNMF_MODE_VALID: H as for tnmf_hip_update_H (row stride honoured); the lateral terms are
+ * kernel0 / kernel1 / kernel2: HOST pointers to the odd-length 1-D kernels of the shift axes, first axis first (ndim == 1:
+ * kernel0 only, ndim == 2: kernel0 and kernel1), ignored when both strengths are 0.  mode == TNMF_MODE_VALID: H as for tnmf_hip_update_H (row stride honoured); the lateral terms are
  * computed by one kernel and enter the epilogue of the fused update (split kernel on row-padded H, generic kernels) or,
  * for the other families, one update kernel behind the unfused gradient.  Other modes: H is C-contiguous with the mode's
  * shift shape; the library pads it (work arrays of its own), runs the 'valid' kernels and applies fold + update in one
- * kernel.  R_scratch: device buffer [N,C,*D] or NULL. */
+ * kernel.  R_scratch: device buffer [N,C,*D] or NULL.  Volumes (ndim == 3): the same step on the volume kernels -- three
+ * passes of the 1-D convolution and one kernel for the lateral terms, pad / fold for the padded modes, one update kernel. */
 int tnmf_hip_update_H_ex(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *V, const void *W,
                          void *H_inout, void *R_scratch, double eps, double sparsity, double inhibition,
                          double cross_inhibition, const double *kernel0, int len0, const double *kernel1, int len1,
-                         void *stream);
+                         const double *kernel2, int len2, void *stream);
 
 /* Local part of TransformInvariantNMF._update_W (TransformInvariantNMF.py:240-241 / :444-448):
  *   negpos[0] = neg_W, negpos[1] = pos_W as one contiguous [2,M,C,*A] buffer (what the all-reduce carries).

@@ -148,21 +148,44 @@ def test_volume_fit_f32_within_the_parity_bar():
     assert abs(nmf._energy_function() - ref.energy()) / ref.energy() < 1e-5
 
 
-def test_volume_steps_outside_the_library_answer_unsupported():
-    """tnmf_hip_update_H_ex / tnmf_hip_run_schedule cover one and two shift axes; for volumes they refuse before touching
-    anything and the front end composes the step (the fits above)."""
+def test_volume_half_steps_run_inside_the_library():
+    """Lateral terms and padded modes of volumes go through tnmf_hip_update_H_ex (three passes of the 1-D convolution, the
+    lateral-term kernel, pad / fold, one update kernel) -- counted here; tnmf_hip_run_schedule covers one and two shift
+    axes and refuses volumes before touching anything (the front end drives the schedules step by step)."""
     import ctypes
     from tnmf_amd import _lib
-    V = _volume(N=2, C=1, D=(4, 5, 6)).astype(np.float32)
-    be = HIP_Backend()
-    np.random.seed(0)
-    W, H = be.initialize(V, (2, 2, 2), 2, None, (-3, -2, -1))
+    V = _volume(N=2, C=1, D=(5, 6, 7))
+    nmf = TransformInvariantNMF(n_atoms=2, atom_shape=(2, 2, 3), backend='hip', reconstruction_mode='circular')
+    be = nmf._backend
+    calls = []
+    lib = be._lib
+    inner = lib.tnmf_hip_update_H_ex
+
+    class Spy:   # (ctypes function objects cannot be patched in place)
+        def __getattr__(self, name):
+            if name == 'tnmf_hip_update_H_ex':
+                def counted(*a):
+                    calls.append(1)
+                    return inner(*a)
+                return counted
+            return getattr(lib, name)
+
+    be._lib = Spy()
+    try:
+        np.random.seed(42)
+        nmf.fit(V, n_iterations=3, inhibition_strength=0.1, cross_atom_inhibition_strength=0.05)
+    finally:
+        be._lib = lib
+    assert len(calls) == 3, 'the H half steps did not go through tnmf_hip_update_H_ex'
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=2, atom_shape=(2, 2, 3), reconstruction_mode='circular')
+    ref.fit(V, n_iterations=3, inhibition_strength=0.1, cross_atom_inhibition_strength=0.05)
+    np.testing.assert_allclose(nmf.H, ref.H, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(nmf.W, ref.W, rtol=1e-9, atol=1e-12)
+
+    W, H = nmf._W, nmf._H
     before = be.to_ndarray(H).copy()
     g = be._geom(2, 2)
-    one = (ctypes.c_double * 1)(1.0)
-    rc = be._lib.tnmf_hip_update_H_ex(be._ctx, ctypes.byref(g), 0, be._V_dev.data_ptr(), W.data_ptr(), H.data_ptr(), None,
-                                      1e-9, 0.0, 0.1, 0.0, one, 1, one, 1, None)
-    assert rc == _lib.E_UNSUPPORTED
     acc = be.new_gradient_accumulator(W)
     ops = (_lib.Op * 1)()
     rc = be._lib.tnmf_hip_run_schedule(be._ctx, ctypes.byref(g), be._V_dev.data_ptr(), W.data_ptr(), H.data_ptr(), None,

@@ -99,7 +99,7 @@ def load() -> ctypes.CDLL:
     lib.tnmf_hip_convolve_axis.argtypes = [vp, ci, sz, ci, sz, vp, vp, ctypes.POINTER(cd), ci, vp]
     lib.tnmf_hip_update_H.argtypes = [vp, gp, vp, vp, vp, vp, ci, cd, cd, vp]
     lib.tnmf_hip_update_H_ex.argtypes = [vp, gp, ci, vp, vp, vp, vp, cd, cd, cd, cd, ctypes.POINTER(cd), ci,
-                                         ctypes.POINTER(cd), ci, vp]
+                                         ctypes.POINTER(cd), ci, ctypes.POINTER(cd), ci, vp]
     lib.tnmf_hip_run_schedule.argtypes = [vp, gp, vp, vp, vp, vp, vp, ctypes.POINTER(Op), ci, cd, cd, vp]
     lib.tnmf_hip_grad_W_fused.argtypes = [vp, gp, vp, vp, vp, vp, ci, vp, vp]
     lib.tnmf_hip_apply_W.argtypes = [vp, gp, vp, vp, cd, vp]

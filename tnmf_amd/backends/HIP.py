@@ -550,13 +550,11 @@ class HIP_Backend(Backend):
         lateral = inhibition > 0 or cross_inhibition > 0
         if self._mode != 0 or lateral:
             k = len(self.atom_shape)
-            if k == 3:   # (tnmf_hip_update_H_ex covers one and two shift axes: the front end composes the step for volumes)
-                raise NotImplementedError('lateral terms / reconstruction modes of volumes outside the fused kernel')
             ks = [np.ascontiguousarray(kk, dtype=np.float64) for kk in (inhibition_kernels or ())]
             if lateral and len(ks) != k:
                 raise ValueError('one inhibition kernel per shift axis')
-            kp = [kk.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for kk in ks] + [None, None]
-            kl = [len(kk) for kk in ks] + [0, 0]
+            kp = [kk.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for kk in ks] + [None, None, None]
+            kl = [len(kk) for kk in ks] + [0, 0, 0]
             Rs = self._R_scratch[ls]
             if self._mode == 0:
                 self._validate_H_cache(Hs, W)   # (the library drops the spectra of the samples it updates itself)
@@ -568,7 +566,7 @@ class HIP_Backend(Backend):
                     rc = self._lib.tnmf_hip_update_H_ex(
                         self._ctx, ctypes.byref(self._geom(Hc.shape[0], W.shape[0], ld)), self._mode, _ptr(Vs), _ptr(W),
                         _ptr(Hc), _ptr(Rs), float(eps), float(sparsity), float(inhibition), float(cross_inhibition),
-                        kp[0], kl[0], kp[1], kl[1], self._stream())
+                        kp[0], kl[0], kp[1], kl[1], kp[2], kl[2], self._stream())
                 return rc, 'tnmf_hip_update_H_ex'
 
             # (inhibition kernels too long for the lateral-term kernel's LDS tile, or planes beyond its 32-bit offsets: the

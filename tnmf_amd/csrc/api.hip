@@ -374,6 +374,65 @@ int vol_api_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V
     return vol_corr_W(v, dtype, V, Rs, W, H_inout, nullptr, nullptr, true, reg, s);
 }
 
+// TransformInvariantNMF._update_H in full for volumes: the lateral terms (three passes of the 1-D convolution, then
+// k_vol_lateral) and the padded modes (pad, 'valid' kernels, fold) on work arrays of the library, one update kernel
+int vol_api_update_H_ex(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *V, const void *W,
+                        void *H_inout, void *R_scratch, double eps, double sparsity, double inhibition,
+                        double cross_inhibition, const double *const kern[3], const int klen[3], void *stream) {
+    VOL_ENTER(ctx, geom);
+    if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
+    if (v.N == 0) return TNMF_OK;
+    if (!V || !W || !H_inout) return TNMF_E_NULL;
+    if (inhibition < 0 || cross_inhibition < 0) return TNMF_E_GEOM;
+    const bool lateral = inhibition > 0 || cross_inhibition > 0;
+    if (lateral)
+        for (int i = 0; i < 3; ++i) {
+            if (!kern[i]) return TNMF_E_NULL;
+            if (klen[i] < 1 || klen[i] > kMaxTaps || !(klen[i] & 1)) return TNMF_E_UNSUPPORTED;
+        }
+    const double reg = eps + (sparsity > 0 ? sparsity : 0.0);   // TransformInvariantNMF.py:227-230
+    const double xc = cross_inhibition > 0 && v.M > 1 ? cross_inhibition / (v.M - 1) : 0.0;   // (:266-268)
+    if (mode == TNMF_MODE_VALID && !lateral)
+        return vol_api_update_H(ctx, geom, V, W, H_inout, R_scratch, 0, eps, sparsity, stream);
+    int S[3];
+    for (int i = 0; i < 3; ++i) {
+        S[i] = mode == TNMF_MODE_VALID ? v.H[i] : (mode == TNMF_MODE_FULL ? v.D[i] - v.A[i] + 1 : v.D[i]);
+        if (S[i] < 1) return TNMF_E_GEOM;
+    }
+    const size_t es = esize(dtype), planes = (size_t)v.N * v.M;
+    const size_t svox = (size_t)S[0] * S[1] * S[2];
+    const size_t nS = align_up(planes * svox * es, 256), nP = align_up(planes * vol_hvox(v) * es, 256);
+    // work arrays: [G0 | G1] (lateral), [neg | pos] in the mode's shape, and for the padded modes [Hp | negp | posp]
+    const size_t lat = lateral ? 2 * nS : 0, pad = mode == TNMF_MODE_VALID ? 0 : 3 * nP;
+    CHECK(ensure_hwork(ctx, lat + 2 * nS + pad));
+    char *G0 = static_cast<char *>(ctx->hw), *G1 = G0 + nS;
+    char *neg = static_cast<char *>(ctx->hw) + lat, *pos = neg + nS;
+    char *Hp = pos + nS, *negp = Hp + nP, *posp = negp + nP;
+    void *Rs = R_scratch;
+    if (!Rs) CHECK(vol_scratch(ctx, v, dtype, &Rs, nullptr));
+    const void *E = nullptr;
+    if (lateral) {
+        // first shift axis first (_NumPyBackend.py:60-62): H -> G0 -> G1 -> G0
+        CHECK(launch_convolve_axis(ctx, dtype, H_inout, G0, planes, S[0], S[1] * S[2], kern[0], klen[0], s));
+        CHECK(launch_convolve_axis(ctx, dtype, G0, G1, planes * S[0], S[1], S[2], kern[1], klen[1], s));
+        CHECK(launch_convolve_axis(ctx, dtype, G1, G0, planes * S[0] * S[1], S[2], 1, kern[2], klen[2], s));
+        CHECK(vol_lateral(ctx, dtype, (size_t)v.N, v.M, svox, G0, H_inout, inhibition, xc, s));
+        E = G0;
+    }
+    if (mode == TNMF_MODE_VALID) {
+        CHECK(vol_reconstruct(v, dtype, W, H_inout, Rs, s));
+        CHECK(vol_corr_W(v, dtype, V, Rs, W, nullptr, neg, pos, false, 0.0, s));
+    } else {
+        CHECK(vol_pad_fold(ctx, v, dtype, mode, false, H_inout, Hp, s));
+        CHECK(vol_reconstruct(v, dtype, W, Hp, Rs, s));
+        CHECK(vol_corr_W(v, dtype, V, Rs, W, nullptr, negp, posp, false, 0.0, s));
+        CHECK(vol_pad_fold(ctx, v, dtype, mode, true, negp, neg, s));
+        CHECK(vol_pad_fold(ctx, v, dtype, mode, true, posp, pos, s));
+    }
+    // H <- H * neg / (pos + E + reg): every array is C-contiguous in the mode's shift shape (rows of S[2] elements)
+    return launch_mu_update_extra(ctx, dtype, H_inout, neg, pos, E, planes * S[0] * S[1], S[2], S[2], reg, s);
+}
+
 int vol_api_pad_fold(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, bool fold, const void *in, void *out,
                      void *stream) {
     VOL_ENTER(ctx, geom);
@@ -710,9 +769,15 @@ int tnmf_hip_update_H(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *
 int tnmf_hip_update_H_ex(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, const void *V, const void *W,
                          void *H_inout, void *R_scratch, double eps, double sparsity, double inhibition,
                          double cross_inhibition, const double *kernel0, int len0, const double *kernel1, int len1,
-                         void *stream) {
-    // (volumes: the caller composes the half step from the primitives, tnmf_hip_convolve_axis and tnmf_hip_mu_update)
-    if (is_vol(geom)) return ctx ? TNMF_E_UNSUPPORTED : TNMF_E_NULL;
+                         const double *kernel2, int len2, void *stream) {
+    if (is_vol(geom)) {
+        const double *const kern[3] = {kernel0, kernel1, kernel2};
+        const int klen[3] = {len0, len1, len2};
+        return vol_api_update_H_ex(ctx, geom, mode, V, W, H_inout, R_scratch, eps, sparsity, inhibition, cross_inhibition,
+                                   kern, klen, stream);
+    }
+    (void)kernel2;
+    (void)len2;
     ENTER(ctx, geom);
     if (mode < TNMF_MODE_VALID || mode > TNMF_MODE_REFLECT) return TNMF_E_UNSUPPORTED;
     if (g.N == 0) return TNMF_OK;

@@ -20,3 +20,6 @@ int vol_corr_H(const Vol &v, int dtype, const void *V, const void *R, const void
                double *partials, int P, hipStream_t s);
 int vol_pad_fold(const tnmf_hip_ctx *ctx, const Vol &v, int dtype, int mode, bool fold, const void *in, void *out,
                  hipStream_t s);
+// G [N][M][vox] <- inh * (G - H) + xc * (sum over the atoms of G - G), in place (H laid out like G)
+int vol_lateral(const tnmf_hip_ctx *ctx, int dtype, size_t N, int M, size_t vox, void *G, const void *H, double inh,
+                double xc, hipStream_t s);

@@ -220,6 +220,24 @@ __global__ void k_vol_fold(size_t planes, Vol3 q, int mode, const T *__restrict_
     }
 }
 
+// lateral terms of the H half step (TransformInvariantNMF.py:253-269), in place:  G <- inh * (G - H) + xc * (sum_m G - G)
+// one thread per (sample, voxel), the atoms walked twice (the second pass re-reads what the first just touched)
+template <typename T>
+__global__ void k_vol_lateral(size_t N, int M, size_t vox, T *__restrict__ G, const T *__restrict__ H, T inh, T xc) {
+    const size_t total = N * vox, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const size_t n = e / vox, o0 = n * M * vox + (e - n * vox);
+        T S = 0;
+        if (xc != T(0))
+            for (int m = 0; m < M; ++m) S += G[o0 + (size_t)m * vox];
+        for (int m = 0; m < M; ++m) {
+            const size_t o = o0 + (size_t)m * vox;
+            const T gv = G[o];
+            G[o] = inh * (gv - H[o]) + xc * (S - gv);
+        }
+    }
+}
+
 // every index inside one volume is an int; volumes times samples go through size_t
 bool vol_fits(const Vol &v) {
     const long long lim = 0x7fffffffLL;
@@ -328,6 +346,23 @@ int vol_pad_fold(const tnmf_hip_ctx *ctx, const Vol &v, int dtype, int mode, boo
         if (fold) hipLaunchKernelGGL(k_vol_fold<double>, grid, dim3(kVolBlock), 0, s, planes, q, mode, (const double *)in, (double *)out);
         else hipLaunchKernelGGL(k_vol_pad<double>, grid, dim3(kVolBlock), 0, s, planes, q, mode, (const double *)in, (double *)out);
     }
+    TNMF_LAUNCH_CHECK();
+    return TNMF_OK;
+}
+
+int vol_lateral(const tnmf_hip_ctx *ctx, int dtype, size_t N, int M, size_t vox, void *G, const void *H, double inh,
+                double xc, hipStream_t s) {
+    const size_t total = N * vox;
+    if (total == 0) return TNMF_OK;
+    size_t blocks = (total + kVolBlock - 1) / kVolBlock;
+    const size_t cap = (size_t)ctx->num_cu * 32;
+    if (blocks > cap) blocks = cap;
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_vol_lateral<float>, dim3((unsigned)blocks), dim3(kVolBlock), 0, s, N, M, vox, (float *)G,
+                           (const float *)H, (float)inh, (float)xc);
+    else
+        hipLaunchKernelGGL(k_vol_lateral<double>, dim3((unsigned)blocks), dim3(kVolBlock), 0, s, N, M, vox, (double *)G,
+                           (const double *)H, inh, xc);
     TNMF_LAUNCH_CHECK();
     return TNMF_OK;
 }
