@@ -170,9 +170,8 @@ int tnmf_hip_convolve_axis(tnmf_hip_ctx *ctx, int dtype, size_t rows, int len, s
  * one to three in PyTorch (tnmf/backends/PyTorch.py:13-17: conv1d / conv2d / conv3d).  With ndim == 3 the entry points
  * tnmf_hip_reconstruct, _grad_H, _grad_W, _grad_W_fused, _update_H, _apply_W, _normalize_W, _energy, _pad_H, _fold_H and
  * _ctx_reserve run direct kernels of their own (float32 and float64, C-contiguous activations: h_row_stride 0 or the
- * shift width), and so does tnmf_hip_update_H_ex; _mu_update, _axpby, _sum_parts and _convolve_axis do not look at the
- * geometry.  tnmf_hip_run_schedule answers TNMF_E_UNSUPPORTED (the caller drives the schedules step by step);
- * tnmf_hip_ctx_bind is accepted and has nothing to do.  tnmf_hip_ctx_last_path reads "volume". */
+ * shift width), and so do tnmf_hip_update_H_ex and tnmf_hip_run_schedule (one launch chain per list); _mu_update, _axpby,
+ * _sum_parts and _convolve_axis do not look at the geometry.  tnmf_hip_ctx_bind is accepted and has nothing to do.  tnmf_hip_ctx_last_path reads "volume". */
 
 /* ---- reconstruction modes other than 'valid' --------------------------------------------------------------------
  * Every mode of the reference is a 'valid' reconstruction of padded activations (padding table:

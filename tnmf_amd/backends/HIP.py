@@ -615,7 +615,7 @@ class HIP_Backend(Backend):
     def supports_schedules(self) -> bool:
         """tnmf_hip_run_schedule covers 'valid' mode on one device (with several ranks the W gradient must cross the
         collective between two of its operations)."""
-        return self._mode == 0 and self._world == 1 and len(self.atom_shape or ()) < 3
+        return self._mode == 0 and self._world == 1
 
     def prefers_schedule(self, H: torch.Tensor) -> bool:
         """A whole problem this small is bound by launch latency (BASELINE config 1: 0.34 ms per iteration for 0.1 ms of

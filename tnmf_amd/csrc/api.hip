@@ -202,12 +202,12 @@ bool use_mfma(const tnmf_hip_ctx *ctx, const Geo &g, int dtype, Prim prim) {
 
 // scratch of a volume call: [R of the slice | energy partials + result | partial sums of the W gradient]
 int vol_scratch(tnmf_hip_ctx *ctx, const Vol &v, int dtype, void **R, double **red, double **part = nullptr,
-                int *P = nullptr) {
+                int *P = nullptr, size_t extra = 0) {
     const size_t r_bytes = align_up((size_t)v.N * v.C * vol_vox(v) * esize(dtype), 256);
     const size_t e_bytes = align_up((size_t)(kEnergyPartials + 8) * sizeof(double), 256);
     const int chunks = vol_corr_H_chunks(ctx, v);
     const size_t p_bytes = align_up((size_t)chunks * v.M * v.C * vol_avox(v) * 2 * sizeof(double), 256);
-    const int rc = ensure_scratch(ctx, r_bytes + e_bytes + p_bytes);
+    const int rc = ensure_scratch(ctx, r_bytes + e_bytes + p_bytes + extra);   // (extra: behind the partial sums)
     if (rc != TNMF_OK) return rc;
     if (R) *R = ws_at(ctx, 0);
     if (red) *red = reinterpret_cast<double *>(ws_at(ctx, r_bytes));
@@ -431,6 +431,63 @@ int vol_api_update_H_ex(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, 
     }
     // H <- H * neg / (pos + E + reg): every array is C-contiguous in the mode's shift shape (rows of S[2] elements)
     return launch_mu_update_extra(ctx, dtype, H_inout, neg, pos, E, planes * S[0] * S[1], S[2], S[2], reg, s);
+}
+
+// a list of operations on slices of the resident volume problem (tnmf_hip_run_schedule): one host call, one launch chain
+int vol_api_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, void *W_inout, void *H_inout,
+                         void *R_scratch, void *acc, const tnmf_hip_op *ops, int n_ops, double eps, double sparsity,
+                         void *stream) {
+    VOL_ENTER(ctx, geom);
+    if (n_ops < 0 || (n_ops > 0 && !ops)) return TNMF_E_NULL;
+    if (!V || !W_inout || !H_inout || !acc) return TNMF_E_NULL;
+    const size_t es = esize(dtype);
+    const size_t vs = (size_t)v.C * vol_vox(v) * es, hs = (size_t)v.M * vol_hvox(v) * es;
+    const size_t wn = (size_t)v.M * v.C * vol_avox(v);
+    int nmax = 0;
+    for (int i = 0; i < n_ops; ++i) {
+        if (ops[i].n0 < 0 || ops[i].n1 < ops[i].n0 || ops[i].n1 > v.N) return TNMF_E_GEOM;
+        if (ops[i].n1 - ops[i].n0 > nmax) nmax = ops[i].n1 - ops[i].n0;
+    }
+    const double reg = eps + (sparsity > 0 ? sparsity : 0.0);   // TransformInvariantNMF.py:227-230
+    // scratch for the largest slice: [R | energy words | partial sums of the W gradient], and one gradient behind it
+    Vol vmax = v;
+    vmax.N = nmax;
+    void *Rws;
+    double *part;
+    int Pmax;
+    CHECK(vol_scratch(ctx, vmax, dtype, &Rws, nullptr, &part, &Pmax, align_up(2 * wn * es, 256)));
+    char *grad = reinterpret_cast<char *>(part) + align_up((size_t)Pmax * wn * 2 * sizeof(double), 256);
+    const Geo dict = vol_dict_geo(v);
+    for (int i = 0; i < n_ops; ++i) {
+        const tnmf_hip_op &op = ops[i];
+        Vol vs_ = v;
+        vs_.N = op.n1 - op.n0;
+        const char *Vb = static_cast<const char *>(V) + (size_t)op.n0 * vs;
+        char *Hb = static_cast<char *>(H_inout) + (size_t)op.n0 * hs;
+        void *Rb = R_scratch ? static_cast<void *>(static_cast<char *>(R_scratch) + (size_t)op.n0 * vs) : Rws;
+        switch (op.kind) {
+            case TNMF_OP_UPDATE_H:
+                if (vs_.N == 0) break;
+                CHECK(vol_reconstruct(vs_, dtype, W_inout, Hb, Rb, s));
+                CHECK(vol_corr_W(vs_, dtype, Vb, Rb, W_inout, Hb, nullptr, nullptr, true, reg, s));
+                break;
+            case TNMF_OP_GRAD_W: {
+                if (vs_.N > 0) CHECK(vol_reconstruct(vs_, dtype, W_inout, Hb, Rb, s));
+                int P = vol_corr_H_chunks(ctx, vs_);
+                if (P > Pmax) P = Pmax;   // (the chunk count grows with the slice: never beyond the largest one's)
+                CHECK(vol_corr_H(vs_, dtype, Vb, Rb, Hb, grad, grad + wn * es, part, P, s));
+                CHECK(launch_axpby(ctx, dtype, acc, grad, op.a, op.b, 2 * wn, s));
+                break;
+            }
+            case TNMF_OP_APPLY_W: {
+                char *np = static_cast<char *>(acc);
+                CHECK(launch_apply_normalize_W(dict, dtype, W_inout, np, np + wn * es, eps, true, s));
+                break;
+            }
+            default: return TNMF_E_UNSUPPORTED;
+        }
+    }
+    return TNMF_OK;
 }
 
 int vol_api_pad_fold(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, int mode, bool fold, const void *in, void *out,
@@ -871,7 +928,8 @@ int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
 int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const void *V, void *W_inout, void *H_inout,
                           void *R_scratch, void *acc, const tnmf_hip_op *ops, int n_ops, double eps, double sparsity,
                           void *stream) {
-    if (is_vol(geom)) return ctx ? TNMF_E_UNSUPPORTED : TNMF_E_NULL;   // (volumes: step by step through the primitives)
+    if (is_vol(geom))
+        return vol_api_run_schedule(ctx, geom, V, W_inout, H_inout, R_scratch, acc, ops, n_ops, eps, sparsity, stream);
     ENTER(ctx, geom);
     if (n_ops < 0 || (n_ops > 0 && !ops)) return TNMF_E_NULL;
     if (!V || !W_inout || !H_inout || !acc) return TNMF_E_NULL;
