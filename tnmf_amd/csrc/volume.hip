@@ -34,6 +34,7 @@ __global__ __launch_bounds__(kVolBlock) void k_vol_reconstruct(Vol v, int tiles,
             for (int ay = 0; ay < v.A[1]; ++ay) {
                 const T *hrow = Hm + ((size_t)(z + v.A[0] - 1 - az) * v.H[1] + (y + v.A[1] - 1 - ay)) * v.H[2] + x + v.A[2] - 1;
                 const T *wrow = Wm + (az * v.A[1] + ay) * v.A[2];
+#pragma unroll 4
                 for (int ax = 0; ax < v.A[2]; ++ax) acc += wrow[ax] * hrow[-ax];
             }
     }
