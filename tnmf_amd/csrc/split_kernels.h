@@ -267,22 +267,58 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
     const int nblocks = ONE_D ? tiles_y : g.N * tiles_y;   // row blocks
     const int P = gridDim.x, full = nblocks / P;           // whole rounds of row blocks
     const int left = (nblocks - full * P) * tiles_x;       // tiles of the last, partial round
-    auto stage_coords = [&](int st, int &n, int &u0, int &v0, int &c) {
-        c = st % g.C;
-        const int tl = st / g.C;                                   // tile index within this workgroup's walk
-        int txi, rbk;
-        if (tl < full * tiles_x) {
-            txi = tl % tiles_x;
-            rbk = blockIdx.x + (tl / tiles_x) * P;                 // row block
+    // Coordinates of a stage.  The map from the stage index is full of integer divisions by run-time values (~35 scalar
+    // instructions each, a dozen per stage between stage(), the prefetch set-up and the conversion): the coordinates of the
+    // CURRENT and the NEXT stage are kept in scalar registers and advanced incrementally -- next channel, next column tile --
+    // with the divisions only where a new row block starts.
+    struct SCoord {
+        int st, n, u0, v0, c, tl, txi;
+    };
+    auto coords_div = [&](int st) {
+        SCoord k;
+        k.st = st;
+        k.c = st % g.C;
+        k.tl = st / g.C;                                             // tile index within this workgroup's walk
+        int rbk;
+        if (k.tl < full * tiles_x) {
+            k.txi = k.tl % tiles_x;
+            rbk = blockIdx.x + (k.tl / tiles_x) * P;                 // row block
         } else {
-            const int t = blockIdx.x + (tl - full * tiles_x) * P;  // tile of the partial round
-            txi = t % tiles_x;
+            const int t = blockIdx.x + (k.tl - full * tiles_x) * P;  // tile of the partial round
+            k.txi = t % tiles_x;
             rbk = full * P + t / tiles_x;
         }
         const int tyi = rbk % tiles_y;
-        n = ONE_D ? 0 : rbk / tiles_y;
-        u0 = tyi * SP_TY;
-        v0 = txi * SP_TX;
+        k.n = ONE_D ? 0 : rbk / tiles_y;
+        k.u0 = tyi * SP_TY;
+        k.v0 = k.txi * SP_TX;
+        return k;
+    };
+    auto coords_next = [&](const SCoord &a) {
+        SCoord k = a;
+        k.st = a.st + 1;
+        if (a.c + 1 < g.C) {   // next channel of the same tile
+            k.c = a.c + 1;
+            return k;
+        }
+        k.c = 0;
+        k.tl = a.tl + 1;
+        if (k.tl < full * tiles_x && a.txi + 1 < tiles_x) {   // next column tile of the same row block
+            k.txi = a.txi + 1;
+            k.v0 = a.v0 + SP_TX;
+            return k;
+        }
+        return coords_div(k.st);   // a new row block, or the partial round
+    };
+    SCoord ck[2];   // stage s and stage s + 1 of the walk
+    ck[0] = coords_div(0);
+    ck[1] = coords_next(ck[0]);
+    auto stage_coords = [&](int st, int &n, int &u0, int &v0, int &c) {
+        const SCoord k = st == ck[0].st ? ck[0] : (st == ck[1].st ? ck[1] : coords_div(st));
+        n = k.n;
+        u0 = k.u0;
+        v0 = k.v0;
+        c = k.c;
     };
 
     // staging item of this thread: window row wr, piece wq (elements 4 wq .. 4 wq + 3 of all four copies, which need
@@ -778,10 +814,18 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
         }
     };
     int st = 0;
-    for (int t = 0; t < my_tiles; ++t) {
-        for (int c = 0; c + 1 < g.C; ++c, ++st) stage(std::false_type{}, st);
-        stage(std::true_type{}, st);
+    auto advance = [&]() {
+        ck[0] = ck[1];
+        ck[1] = coords_next(ck[1]);
         ++st;
+    };
+    for (int t = 0; t < my_tiles; ++t) {
+        for (int c = 0; c + 1 < g.C; ++c) {
+            stage(std::false_type{}, st);
+            advance();
+        }
+        stage(std::true_type{}, st);
+        advance();
     }
     if (dbg) {
         SP_STAMP(7);   // wait for H, update arithmetic, store issue of the last stage (the others land in phase 0)
