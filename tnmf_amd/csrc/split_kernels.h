@@ -539,12 +539,13 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
                 hv[rb][4 * q + e] = __builtin_bit_cast(float, w);
             }
         };
-        // memory slot k of the stage: 0..7 the H loads (last channel of a fused update), 8..11 the window prefetch
+        // memory slot k of the stage: 0..3 the window prefetch (consumed first: the conversion runs right behind the loop),
+        // 4..11 the H loads (last channel of a fused update; consumed by the arithmetic behind the exchanges)
         auto mem_slot = [&](int k) {
-            if (k < 8) {
-                if (hload) h_issue(k);
-            } else if (more) {
-                prefetch_issue(k - 8);
+            if (k < 4) {
+                if (more) prefetch_issue(k);
+            } else if (hload) {
+                h_issue(k - 4);
             }
         };
         if (TNMF_ABL(ablate) & 4) {   // (diagnostic builds: no MFMA loop to hide them in)
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
                     // slot i of the k block: the operands of the next one ...
                     if constexpr (next && i < 12) load_a4(bb ^ 1, kb + 1, i & 3, i >> 2);
                     if constexpr (next && i >= 12 && i < 15) load_b_term(bb ^ 1, kb + 1, i - 12);
-                    // ... two memory instructions of the stage in each of the first six k blocks (H loads, then the window) ...
+                    // ... two memory instructions of the stage in each of the first six k blocks (the window, then the H loads) ...
                     if constexpr (kb < 6 && (i == 16 || i == 20)) mem_slot(2 * kb + (i == 20));
                     // ... and the next window, converted and committed piece by piece (behind the last stage the pieces
                     // convert stale registers into the buffer nobody reads: no branch)
