@@ -56,8 +56,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int SP_TY = 8, SP_TX = 32, SP_RB = 2;
+constexpr int SP_TX = 32, SP_RB = 2;
+
+constexpr int split_plane_bytes(int rows, int wstr) { return ((rows * wstr * 2 - 64 + 255) / 256) * 256 + 64; }
 
 // compile-time geometry of one (atom rows, runs per row) instantiation
 // AY == 1 is the 1-D instantiation (signals: one row per sample).  There the ROWS of a tile are eight consecutive SAMPLES
@@ -69,21 +70,27 @@ struct SplitCfg {
     static_assert(!ONE_D || NR4 % 4 == 0, "1-D: whole k blocks of 16 taps");
     static constexpr int WSTR = 4 * NR4 + 28;          // window row stride (bf16 elements): 4 (i >> 2) + b0 + 3 <= WSTR - 1
     static constexpr int Q = WSTR / 4;                 // 4-element pieces per window row
-    static constexpr int SH = SP_TY + AY - 1;          // window rows that hold data
-    static constexpr int SHA = SP_TY + AY;             // + one row of zeros (odd AY: lane half 1 of the last row pair)
-    static constexpr int raw = SHA * WSTR * 2;
-    static constexpr int planeB = ((raw - 64 + 255) / 256) * 256 + 64;   // bytes per (array, copy): == 64 (mod 256)
     static constexpr int NP = (AY + 1) / 2;            // atom row pairs
     static constexpr int NSLOT = ONE_D ? NR4 / 2 : NP * NR4;   // (row pair, run) slots -- 1-D: pairs of runs; a k block holds two
     static constexpr int KB = (NSLOT + 1) / 2;
     static constexpr int wimg = KB * 3 * 1024;         // bytes of the W image of one (atom tile, channel)
+    // Waves per workgroup: four (a tile of 8 rows, two workgroups per CU); EIGHT (16 rows, one W image for twice the pixels)
+    // where a four-wave workgroup needs more than 80 KB of LDS and would sit alone on its CU with ONE wave per SIMD (16 x 16
+    // atoms, the config-5 shard).  A lone wave leaves the matrix pipe idle in every bubble of its own instruction stream --
+    // in-kernel stamps: 47 cycles per MFMA inside the loop where the issue rate is 32, and a fifth of the kernel outside the
+    // loop with nothing running -- and a schedule built for the lone wave (second window buffer filled from inside the
+    // loop, a k block's 24 MFMAs round robin over the four accumulators with the LDS reads dealt between them, 300 registers)
+    // recovered 4 % (30.8 -> 29.5 ms); the eight-wave workgroup, on the plain two-wave schedule, 9.5 % (27.9 ms).
+    static constexpr int lds4 = wimg + 24 * split_plane_bytes(8 + AY, WSTR);
+    static constexpr int lds8 = wimg + 24 * split_plane_bytes(16 + AY, WSTR);
+    static constexpr int WAVES = (!ONE_D && lds4 > 80 * 1024 && lds8 <= 160 * 1024) ? 8 : 4;
+    static constexpr int kBlock = 64 * WAVES, TY = SP_RB * WAVES;
+    static constexpr int SH = TY + AY - 1;             // window rows that hold data
+    static constexpr int SHA = TY + AY;                // + one row of zeros (odd AY: lane half 1 of the last row pair)
+    static constexpr int raw = SHA * WSTR * 2;
+    static constexpr int planeB = split_plane_bytes(SHA, WSTR);   // bytes per (array, copy): == 64 (mod 256)
     static constexpr int win = 24 * planeB;            // 6 arrays x 4 copies
     static constexpr int lds = wimg + win;
-    // One workgroup per CU anyway (more than 80 KB) and room for a second window: the window of the NEXT stage is converted
-    // and committed to the other buffer from inside the MFMA loop instead of between two barriers with the matrix pipe idle
-    // (16 x 16 atoms, config 5: with one wave per SIMD nothing else hides that staging -- 4.8 of 33 ms in the ablations).
-    static constexpr bool DBUF = lds > 80 * 1024 && lds + win <= 160 * 1024;
-    static constexpr int lds_total = lds + (DBUF ? win : 0);
     static constexpr int witems = SH * Q;              // staging items (window row, piece) per stage: one per thread
     static_assert(witems <= kBlock, "one staging item per thread");
     static_assert(planeB % 8 == 0 && planeB % 256 == 64, "copy bases 64 bytes apart modulo the bank row");
@@ -182,7 +189,7 @@ __global__ void k_split_prep_W(Geo g, int NP, int NSLOT, int KB, int one_d, cons
 // inhibition terms of TransformInvariantNMF.py:253-269 (inhibit.hip computes them) -- is loaded behind the MFMA loop,
 // into the registers the operand buffers have just left, and added to pos in the epilogue.
 template <bool FUSED, bool MULTI, int AY, int NR4, bool EXTRA = false>
-__global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_DS_PAIRING void k_split_corr_W(Geo g, int tiles_y, int tiles_x, int ablate,
+__global__ __launch_bounds__((SplitCfg<AY, NR4>::kBlock), 2) TNMF_NO_DS_PAIRING void k_split_corr_W(Geo g, int tiles_y, int tiles_x, int ablate,
                                                             unsigned long long *dbg,
                                                             const float *__restrict__ V, const float *__restrict__ Rr,
                                                             const u32x4 *__restrict__ Wimg, float *__restrict__ Hio,
@@ -191,12 +198,8 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
     static_assert(!EXTRA || FUSED, "the extra denominator term belongs to the fused update");
     using Cfg = SplitCfg<AY, NR4>;
     constexpr int WSTR = Cfg::WSTR, Q = Cfg::Q, planeB = Cfg::planeB, KB = Cfg::KB, NSLOT = Cfg::NSLOT, NP = Cfg::NP;
-    constexpr bool ONE_D = Cfg::ONE_D, DBUF = Cfg::DBUF;
-#ifdef TNMF_SPLIT_SPREAD_ALL
-    constexpr bool SPREAD = true;
-#else
-    constexpr bool SPREAD = Cfg::lds > 80 * 1024;   // one workgroup per CU = one wave per SIMD (see the MFMA loop)
-#endif
+    constexpr bool ONE_D = Cfg::ONE_D;
+    constexpr int kBlock = Cfg::kBlock, SP_TY = Cfg::TY;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Wl = smem;                  // [KB][3][64 lanes][16 bytes]
     unsigned char *Xw = smem + Cfg::wimg;      // [6 arrays: V hi, mid, lo, R hi, mid, lo][4 copies][SHA][WSTR] bf16
@@ -221,8 +224,7 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
     } while (0)
 
     // zero the whole window once: the spare row and the slack of every plane stay zero (finite) for good
-    for (int i = threadIdx.x; i < (DBUF ? 2 : 1) * Cfg::win / 16; i += kBlock)
-        reinterpret_cast<u32x4 *>(Xw)[i] = u32x4{0, 0, 0, 0};
+    for (int i = threadIdx.x; i < Cfg::win / 16; i += kBlock) reinterpret_cast<u32x4 *>(Xw)[i] = u32x4{0, 0, 0, 0};
 
     // W image of one channel: global (L2-resident, pre-split by k_split_prep_W) -> LDS, 16 bytes per thread and piece, in
     // chunks of up to 8 pieces whose loads are all issued before the first store (one memory round trip per chunk, not
@@ -362,23 +364,21 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
     // commit(): registers -> the four shifted LDS copies; touches no global memory, so it waits for nothing.
     unsigned tp[6][4];   // [V hi, V mid, V lo, R hi, R mid, R lo][element pair (0,1) (2,3) (4,5) (6,-)]
     unsigned tq[6][3];   // the odd pairs (1,2) (3,4) (5,6) for the copies shifted by 1 and 3
-    // The conversion comes in PIECES (pieces 0 .. kConvPieces-1, then the commit of the six arrays) so that the double-buffered
-    // flavour can deal them over consecutive groups of its MFMA loop, a few vector instructions per MFMA gap.
-    float cfv[7], cfr[7];   // the window values of this thread's item, masked
-    auto convert_select = [&](int st) {
+    auto convert = [&](int st) {
         int n, u0, v0, c;
         stage_coords(st, n, u0, v0, c);
         const int y = u0 + wr - (g.Ay - 1);
         const bool yok = ONE_D ? u0 + wr < g.N : (y >= 0 && y < g.Dy);
         const int x0 = v0 + 4 * wq - (g.Ax - 1);
+        float fv[7], fr[7];
         // wave-uniform: every 4-column piece of this tile's window lies inside the image row (the second piece of the
         // last item ends at window column WSTR + 3) -> no start column was clamped, the pieces sit where they belong
         const bool xin = v0 - (g.Ax - 1) >= 0 && v0 - (g.Ax - 1) + WSTR + 4 <= g.Dx;
         if (xin) {
 #pragma unroll
             for (int e = 0; e < 7; ++e) {
-                cfv[e] = yok ? pw[e >> 2][e & 3] : 0.f;
-                cfr[e] = yok ? pw[2 + (e >> 2)][e & 3] : 0.f;
+                fv[e] = yok ? pw[e >> 2][e & 3] : 0.f;
+                fr[e] = yok ? pw[2 + (e >> 2)][e & 3] : 0.f;
             }
         } else {
 #pragma unroll
@@ -390,55 +390,34 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
                 const f32x4 a = pw[e >> 2], b = pw[2 + (e >> 2)];
                 const float va = d == 0 ? a[0] : d == 1 ? a[1] : d == 2 ? a[2] : a[3];
                 const float vb = d == 0 ? b[0] : d == 1 ? b[1] : d == 2 ? b[2] : b[3];
-                cfv[e] = ok ? va : 0.f;
-                cfr[e] = ok ? vb : 0.f;
+                fv[e] = ok ? va : 0.f;
+                fr[e] = ok ? vb : 0.f;
             }
         }
-    };
-    // element pair k = (0,1) (2,3) (4,5) (6,-) of the three term arrays of V (which = 0) or R (1), converted two at a time
-    auto convert_pair = [&](int which, int k) {
-        const float *f = which ? cfr : cfv;
-        split3_pair(f[2 * k], k < 3 ? f[2 * k + 1] : 0.f, tp[3 * which][k], tp[3 * which + 1][k], tp[3 * which + 2][k]);
-    };
-    // the odd pairs (1,2) (3,4) (5,6) of array ar: one funnel shift each
-    auto convert_odd = [&](int ar) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tq[ar][k] = (tp[ar][k] >> 16) | (tp[ar][k + 1] << 16);
-    };
-    auto convert = [&](int st) {
-        convert_select(st);
+        // element pairs (0,1) (2,3) (4,5) (6,-) of the six term arrays, converted two at a time
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            convert_pair(0, k);
-            convert_pair(1, k);
+            split3_pair(fv[2 * k], k < 3 ? fv[2 * k + 1] : 0.f, tp[0][k], tp[1][k], tp[2][k]);
+            split3_pair(fr[2 * k], k < 3 ? fr[2 * k + 1] : 0.f, tp[3][k], tp[4][k], tp[5][k]);
         }
+        // the odd pairs (1,2) (3,4) (5,6): one funnel shift each
 #pragma unroll
-        for (int ar = 0; ar < 6; ++ar) convert_odd(ar);
-    };
-    auto commit_array = [&](int buf, int ar) {   // copy s holds window elements s .. s+3 of this piece
-        // (DBUF: no branch -- the threads beyond the last item repeat item 0 with item 0's own values -- so that the stores
-        // stay inside the basic block of the MFMAs they are scheduled between)
-        if (DBUF || threadIdx.x < Cfg::witems) {
-            unsigned char *dst = Xw + buf * Cfg::win + (wr * WSTR + 4 * wq) * 2;
-            *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 0) * planeB) = u32x2{tp[ar][0], tp[ar][1]};
-            *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 1) * planeB) = u32x2{tq[ar][0], tq[ar][1]};
-            *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 2) * planeB) = u32x2{tp[ar][1], tp[ar][2]};
-            *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 3) * planeB) = u32x2{tq[ar][1], tq[ar][2]};
-        }
-    };
-    // piece i of (convert + commit) of stage st into window buffer buf: 0 select, 1..8 the pairs, 9..14 odd pairs + commit
-    constexpr int kStagePieces = 15;
-    auto stage_piece = [&](int st, int buf, int i) {
-        if (i == 0) convert_select(st);
-        else if (i <= 8) convert_pair((i - 1) & 1, (i - 1) >> 1);
-        else {
-            convert_odd(i - 9);
-            commit_array(buf, i - 9);
-        }
-    };
-    auto commit = [&](int buf) {   // buf: window buffer (0 unless DBUF)
+        for (int ar = 0; ar < 6; ++ar)
 #pragma unroll
-        for (int ar = 0; ar < 6; ++ar) commit_array(buf, ar);
+            for (int k = 0; k < 3; ++k) tq[ar][k] = (tp[ar][k] >> 16) | (tp[ar][k + 1] << 16);
+    };
+    auto commit = [&]() {
+        if (threadIdx.x < Cfg::witems) {
+            unsigned char *dst = Xw + (wr * WSTR + 4 * wq) * 2;
+#pragma unroll
+            for (int ar = 0; ar < 6; ++ar) {
+                // copy s holds window elements s .. s+3 of this piece
+                *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 0) * planeB) = u32x2{tp[ar][0], tp[ar][1]};
+                *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 1) * planeB) = u32x2{tq[ar][0], tq[ar][1]};
+                *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 2) * planeB) = u32x2{tp[ar][1], tp[ar][2]};
+                *reinterpret_cast<u32x2 *>(dst + (ar * 4 + 3) * planeB) = u32x2{tq[ar][1], tq[ar][2]};
+            }
+        }
     };
 
     const int my_tiles = full * tiles_x + ((int)blockIdx.x < left ? (left - blockIdx.x + P - 1) / P : 0);
@@ -486,9 +465,7 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
                 store_W(ch);
             }
         }
-        // (DBUF: the window of every stage but the first was committed from inside the previous stage's MFMA loop; barrier 1
-        // above made it visible)
-        if (!(TNMF_ABL(ablate) & 1) && (!DBUF || st == 0)) commit(0);
+        if (!(TNMF_ABL(ablate) & 1)) commit();
         lds_barrier();
         SP_STAMP(2);     // commit + barrier 2
         const bool more = st + 1 < my_stages && !(TNMF_ABL(ablate) & 1);
@@ -560,7 +537,6 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
             constexpr int G = KB * 4;
             u32x2 a[2][3][2];   // [buffer][term][run of the k block]
             u32x4 b[2][3];      // [buffer][term]
-            const unsigned char *ab = DBUF ? abase + (st & 1) * Cfg::win : abase;   // this stage's window buffer
             auto load_a = [&](int buf, int gi) {
                 const int kb = gi >> 2, rb = (gi >> 1) & 1, x = gi & 1;
 #pragma unroll
@@ -572,17 +548,14 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
                     const int off = ONE_D ? (rb * WSTR + 16 * kb + 4 * e) * 2 : ((rb + 2 * p) * WSTR + 4 * r) * 2;
 #pragma unroll
                     for (int term = 0; term < 3; ++term)
-                        a[buf][term][e] = *reinterpret_cast<const u32x2 *>(ab + (3 * x + term) * 4 * planeB + off);
+                        a[buf][term][e] = *reinterpret_cast<const u32x2 *>(abase + (3 * x + term) * 4 * planeB + off);
                 }
-            };
-            auto load_b_term = [&](int buf, int kb, int term) {
-                b[buf][term] = *reinterpret_cast<const u32x4 *>(bbase + (kb * 3 + term) * 1024);
             };
             auto load_b = [&](int buf, int kb) {
 #pragma unroll
-                for (int term = 0; term < 3; ++term) load_b_term(buf, kb, term);
+                for (int term = 0; term < 3; ++term)
+                    b[buf][term] = *reinterpret_cast<const u32x4 *>(bbase + (kb * 3 + term) * 1024);
             };
-            if constexpr (!SPREAD) {
             load_b(0, 0);
             load_a(0, 0);
             // the wave inside its MFMA loop outranks its SIMD partner, which is in its epilogue most of that time (VALU issue is
@@ -596,8 +569,8 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
                 constexpr int MSTRIDE = G >= 24 ? G / 24 : 1;
                 if constexpr (gi + 1 < G) load_a(ab ^ 1, gi + 1);
                 if constexpr (nextb) load_b(bb ^ 1, kb + 1);
-                // one memory instruction of the stage per group, over the first part of the loop (H loads first: the
-                // epilogue right behind the loop needs them; then the next window, needed one barrier later)
+                // one memory instruction of the stage per group, over the first part of the loop (mem_slot: the next window
+                // first, then the H values of the epilogue)
                 if constexpr (gi % MSTRIDE == 0 && gi / MSTRIDE < 12) mem_slot(gi / MSTRIDE);
                 __builtin_amdgcn_sched_barrier(0);
                 const bf16x8 ahi = as_bf16x8(a[ab][0][0], a[ab][0][1]);
@@ -623,63 +596,6 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
                 acc[rb][x] = d;
                 __builtin_amdgcn_sched_barrier(0);
             });
-            } else {
-            // ONE wave per SIMD (shapes whose LDS admits one workgroup per CU: 16 x 16 atoms): nobody fills a bubble.  In-kernel
-            // stamps at the config-5 shard showed 47 cycles per MFMA inside the loop of the two-wave schedule above; a bare
-            // chain of six dependent MFMAs costs a lone wave 20 % over the issue rate (tools/probes/mfma_chain_probe.hip),
-            // and the burst of nine LDS reads behind a group ~70 cycles per 192.  So a whole k block is one unit here: its 24
-            // MFMAs go ROUND ROBIN over the four accumulators (a dependent successor is four instructions away), and the 27
-            // LDS reads of the next k block, the stage's memory instructions and the pieces of the next window are dealt one
-            // at a time into the gaps BETWEEN them -- every placement fenced.
-            static_assert(!SPREAD || (G == 4 * KB && KB >= 6 && (!DBUF || KB >= 12)),
-                          "whole k blocks; room for the twelve memory slots and the window pieces");
-            u32x2 a4[2][4][3][2];   // [buffer][group of the k block: (row, V | R)][term][run]
-            auto load_a4 = [&](int buf, int kb, int q, int term) {
-                const int rb = q >> 1, x = q & 1;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    int slot = 2 * kb + e;
-                    if (slot >= NSLOT) slot = NSLOT - 1;
-                    const int r = slot / NP, p = slot - r * NP;
-                    const int off = ONE_D ? (rb * WSTR + 16 * kb + 4 * e) * 2 : ((rb + 2 * p) * WSTR + 4 * r) * 2;
-                    a4[buf][q][term][e] = *reinterpret_cast<const u32x2 *>(ab + (3 * x + term) * 4 * planeB + off);
-                }
-            };
-            load_b(0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int term = 0; term < 3; ++term) load_a4(0, 0, q, term);
-            static_for<KB>([&](auto kbc) {
-                constexpr int kb = decltype(kbc)::value, bb = kb & 1;
-                constexpr bool next = kb + 1 < KB;
-                const bf16x8 bt[3] = {__builtin_bit_cast(bf16x8, b[bb][0]), __builtin_bit_cast(bf16x8, b[bb][1]),
-                                      __builtin_bit_cast(bf16x8, b[bb][2])};
-                f32x16 d[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) d[q] = (!MULTI && kb == 0) ? zero16() : acc[q >> 1][q & 1];
-                // product p of the six: (W term, X term), smallest first
-                constexpr int wt[6] = {0, 2, 1, 0, 1, 0}, xt[6] = {2, 0, 1, 1, 0, 0};
-                static_for<24>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value, p = i >> 2, q = i & 3;
-                    d[q] = mfma_bf16(bt[wt[p]], as_bf16x8(a4[bb][q][xt[p]][0], a4[bb][q][xt[p]][1]), d[q]);
-                    // slot i of the k block: the operands of the next one ...
-                    if constexpr (next && i < 12) load_a4(bb ^ 1, kb + 1, i & 3, i >> 2);
-                    if constexpr (next && i >= 12 && i < 15) load_b_term(bb ^ 1, kb + 1, i - 12);
-                    // ... two memory instructions of the stage in each of the first six k blocks (the window, then the H loads) ...
-                    if constexpr (kb < 6 && (i == 16 || i == 20)) mem_slot(2 * kb + (i == 20));
-                    // ... and the next window, converted and committed piece by piece (behind the last stage the pieces
-                    // convert stale registers into the buffer nobody reads: no branch)
-                    if constexpr (DBUF && kb >= KB - 5 && kb < KB - 1 && (i == 15 || i == 17 || i == 19 || i == 21)) {
-                        constexpr int piece = 4 * (kb - (KB - 5)) + (i - 15) / 2;
-                        if constexpr (piece < kStagePieces) stage_piece(st + 1, (st + 1) & 1, piece);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q >> 1][q & 1] = d[q];
-            });
-            }
             __builtin_amdgcn_s_setprio(0);
             // short loops (the 1-D instantiations with few taps: fewer than 12 groups): the memory slots the loop had no
             // group for are issued behind it
@@ -708,7 +624,7 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
                     }
                 }
         }
-        if (!DBUF && more) convert(st + 1);   // before the stores below (see convert)
+        if (more) convert(st + 1);   // before the stores below (see convert)
         SP_STAMP(5);     // convert (the prefetched window has landed under the loop)
 
         if (LAST && !(TNMF_ABL(ablate) & 8)) {
@@ -832,7 +748,7 @@ __global__ __launch_bounds__(kBlock, (SplitCfg<AY, NR4>::DBUF ? 1 : 2)) TNMF_NO_
         SP_STAMP(7);   // wait for H, update arithmetic, store issue of the last stage (the others land in phase 0)
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + k] = phase[k];
+            for (int k = 0; k < 8; ++k) dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * Cfg::WAVES + wave) * 8 + k] = phase[k];
         }
     }
 #undef SP_STAMP
@@ -862,6 +778,7 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
     hipLaunchKernelGGL(k_split_prep_W, dim3(MT * g.C * Cfg::KB), dim3(64), 0, s, g, Cfg::NP, Cfg::NSLOT, Cfg::KB,
                        Cfg::ONE_D ? 1 : 0, W, (u32x4 *)ctx->wimg);
     // (1-D: the rows of a tile are samples: row blocks of eight samples, one "plane")
+    constexpr int kBlock = Cfg::kBlock, SP_TY = Cfg::TY;
     const int tiles_y = Cfg::ONE_D ? cdiv(g.N, SP_TY) : cdiv(g.Hy, SP_TY), tiles_x = cdiv(g.Hx, SP_TX);
     const long nrowblocks = Cfg::ONE_D ? tiles_y : (long)g.N * tiles_y;
     const long ntiles = nrowblocks * tiles_x;
@@ -872,11 +789,11 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
     if (P > ntiles) P = ntiles;   // (row blocks round robin, the last partial round tile by tile)
     const dim3 grid((unsigned)P, MT);
     unsigned long long *dbg = nullptr;
-    const size_t nw = (size_t)P * MT * 4;
+    const size_t nw = (size_t)P * MT * Cfg::WAVES;
     static const bool want_stamps = tnmf_diag_env("TNMF_HIP_STAMPS") != nullptr;   // -DTNMF_DIAG builds only
     if (want_stamps) TNMF_HIP_TRY(hipMalloc(&dbg, nw * 8 * sizeof(unsigned long long)));
 #define SPLIT_LAUNCH(FUSED_, MULTI_, EXTRA_, H_, NEG_, POS_, REG_)                                                   \
-    hipLaunchKernelGGL((k_split_corr_W<FUSED_, MULTI_, AY, NR4, EXTRA_>), grid, dim3(kBlock), Cfg::lds_total, s, g, tiles_y,   \
+    hipLaunchKernelGGL((k_split_corr_W<FUSED_, MULTI_, AY, NR4, EXTRA_>), grid, dim3(kBlock), Cfg::lds, s, g, tiles_y,   \
                        tiles_x, ctx->ablate, dbg, V, R, (const u32x4 *)ctx->wimg, H_, NEG_, POS_, REG_, extra)
     if (fused && extra) {
         if constexpr (!Cfg::ONE_D) {
