@@ -565,6 +565,7 @@ def test_front_end_branches_on_row_padded_activations(kw):
     ('generic', 'valid', True),     # generic fused kernel with the extra term
     ('fft', 'valid', True),         # FFT family: unfused gradient + one update kernel
     ('auto', 'circular', True), ('auto', 'reflect', False), ('auto', 'full', True),
+    ('auto16', 'valid', True),      # 16 x 16 atoms, three channels: the eight-wave workgroups of the split kernel, extra term
 ], ids=lambda v: str(v))
 def test_lateral_terms_and_modes_run_inside_the_library(path, mode, lateral):
     """TransformInvariantNMF._update_H in full (reference :246-271) through tnmf_hip_update_H_ex: lateral inhibition and
@@ -572,6 +573,8 @@ def test_lateral_terms_and_modes_run_inside_the_library(path, mode, lateral):
     fold and update as kernels of the library -- float32, against the float64 oracle's front end."""
     oracle_threads()
     N, C, D, M, A = 4, 1, (96, 80), 32, (12, 12)
+    if path == 'auto16':
+        path, (N, C, D, M, A) = 'auto', (6, 3, (90, 100), 33, (16, 16))
     V = planted_V(N, C, D, M, A, seed=13)
     kw = dict(n_iterations=3, sparsity_H=0.02)
     if lateral:
