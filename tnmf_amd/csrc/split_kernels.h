@@ -30,8 +30,9 @@
 //   W operand (32 atoms x 16 k): W pre-split on the device into the exact register image [k block][term][lane][8 bf16]
 //   (k_split_prep_W), copied to LDS once per workgroup (one channel) or per stage (several), read with ds_read_b128.
 //
-// Workgroup = 4 waves = a tile of 8 rows x 32 columns of the shift plane x 32 atoms; wave w owns rows 2w, 2w+1, for V
-// and for R: 4 accumulators of 32 x 32.  Persistent: a workgroup walks its tiles; while the MFMAs of a stage run, the
+// Workgroup = 4 waves = a tile of 8 rows x 32 columns of the shift plane x 32 atoms (8 waves and 16 rows where four waves
+// would need more than half a CU's LDS: SplitCfg::WAVES); wave w owns rows 2w, 2w+1, for V and for R: 4 accumulators of
+// 32 x 32.  Persistent: a workgroup walks its tiles; while the MFMAs of a stage run, the
 // next stage's (V, R) window is in flight into registers and so are the H values the epilogue will update.
 #pragma once
 #include <cstdio>
