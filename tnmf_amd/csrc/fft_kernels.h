@@ -10,6 +10,7 @@
 #include <atomic>
 #include "fft.h"
 #include "fft_engine.h"
+#include "fft_len_twiddles.h"
 
 namespace {
 
@@ -38,13 +39,13 @@ struct ColTile {
     static constexpr int v = WIDE ? 16 : LenCfg<L>::col_tile;
 };
 
+// the twiddles exp(-2 pi i t / L) of a workgroup's transforms: copied into LDS from the generated table of this length
+// (fft_len_twiddles.h; the double sincospi per entry this replaces was a seventh of the vector instructions of the row
+// transform, and sat in front of its loads)
 template <typename T, int L>
 __device__ __forceinline__ void make_twiddles(cplx<T> *tw, int tid, int nt) {
-    for (int t = tid; t < L; t += nt) {
-        double sn, cs;
-        sincospi(2.0 * t / L, &sn, &cs);
-        tw[t] = {(T)cs, (T)(-sn)};
-    }
+    static_assert(sizeof(tnmf_len_twiddles) == sizeof(double) * 2 * L, "the table of this translation unit's length");
+    for (int t = tid; t < L; t += nt) tw[t] = {(T)tnmf_len_twiddles[t][0], (T)tnmf_len_twiddles[t][1]};
 }
 
 // all NB sequences of the tile, forward; the caller has synchronised the tile, the function ends synchronised
