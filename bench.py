@@ -130,6 +130,33 @@ GROUP_KERNELS = {
 }
 
 
+def csrc_digest():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from: what a committed profile was
+    measured on (tools/final_measure.sh writes it beside the profiles) against what this run executes."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, 'tnmf_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(src, '*.hip')) + glob.glob(os.path.join(src, '*.h')) +
+                    [os.path.join(src, 'Makefile'), os.path.join(ROOT, 'include', 'tnmf_hip.h')]):
+        if os.path.basename(f) == 'fft_len_twiddles.h':   # generated at build time
+            continue
+        h.update(os.path.basename(f).encode() + b'\0' + open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def profile_is_current(path):
+    """True / False: the sources digest recorded with the profile's round (profiles/rNN_sources.sha16) equals / differs
+    from the sources of this run; None when that round recorded none (rounds 1-3)."""
+    if not path:
+        return None
+    stamp = os.path.join(ROOT, 'profiles', os.path.basename(path)[:3] + '_sources.sha16')
+    try:
+        return open(stamp).read().split()[0] == csrc_digest()
+    except (OSError, IndexError):
+        return None
+
+
 def committed_profile(cfg_id, what):
     """Newest committed profiles/rNN_<what>_config<c>.<ext> (config 3 also without the suffix)."""
     import glob
@@ -237,6 +264,23 @@ def cpu_baseline(cfg, budget_s=20.0):
     }
 
 
+def launch_ranks(n):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` as a child process;
+    its stdout (rank 0's JSON line) goes to ours, its exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench.py: starting', ' '.join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -263,7 +307,19 @@ def main():
     ap.add_argument('--no-parity', action='store_true', help='skip the parity leg against the float64 oracle')
     ap.add_argument('--parity-samples', type=int, default=None)
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--legs', default='strong,config4,config5',
+                    help='--gpus N > 1: further timed legs beside the weak-scaling headline, comma separated: strong '
+                         '(config 3, 256 GLOBAL samples, 256 / N per GPU), config4 / config5 (Cyclic-MU epochs on the '
+                         'per-GPU shards of BASELINE configs[3] / configs[4], one collective per epoch); "none" skips them')
+    ap.add_argument('--leg-steps', type=int, default=None, help='timed steps of the further legs (default: min(steps, 20); '
+                    'config5: min(steps, 8))')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Started as plain `python bench.py --gpus N`: this process has not touched the GPU (torch is not even imported
+        # yet) and stays that way -- the N ranks are CHILD processes under torch.distributed.run, one per GPU, and rank
+        # 0's JSON line is relayed.  (Never os.exec* after a GPU call on this pool.)
+        sys.exit(launch_ranks(args.gpus))
 
     # Only the result line may reach stdout: libraries (the RCCL version banner, ...) write to fd 1 from C, so fd 1 is
     # pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end.
@@ -307,12 +363,8 @@ def main():
     k = len(cfg['A'])
 
     # this rank's shard of the synthetic data sits at [rank * n_local, (rank + 1) * n_local) of the global sample axis
-    V_local = synth_V_on_device(cfg, n_local, 1234 + rank, device)
-    if world > 1:
-        V = np.zeros((n_global, cfg['C']) + tuple(cfg['D']), dtype=np.float32)
-        V[rank * n_local:(rank + 1) * n_local] = V_local
-    else:
-        V = V_local
+    # (every rank holds ONLY its own samples: HIP_Backend(sharded_input=True); the global array exists nowhere)
+    V = synth_V_on_device(cfg, n_local, 1234 + rank, device)
 
     F = conv_flops(cfg, n_local)
     Hs = tuple(d + a - 1 for d, a in zip(cfg['D'], cfg['A']))
@@ -385,25 +437,34 @@ def main():
 
     batch_size = batch_size_g
 
-    def run_leg(path, pg, split=True):
-        """args.warmup untimed + args.steps timed steps from the fixed start on kernel family `path`.  A step is one
-        full-batch MU iteration, or (--algorithm cyclic) one Cyclic-MU epoch driven by the front end's epoch function."""
+    def run_leg(path, pg, split=True, leg_cfg=None, leg_V=None, algorithm=None, batch=None, steps=None, warmup=None):
+        """`warmup` untimed + `steps` timed steps from the fixed start on kernel family `path`.  A step is one
+        full-batch MU iteration, or (algorithm cyclic) one Cyclic-MU epoch driven by the front end's epoch function.
+        Defaults: the headline workload (cfg, V, --algorithm, --steps, --warmup); the further legs of an N > 1 run pass
+        their own.  `leg_V` is THIS rank's block of samples."""
+        leg_cfg = cfg if leg_cfg is None else leg_cfg
+        leg_V = V if leg_V is None else leg_V
+        algorithm = args.algorithm if algorithm is None else algorithm
+        batch = batch_size if batch is None else batch
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
         np.random.seed(42)             # same W on every rank
         torch.cuda.manual_seed(4242 + rank)
-        model = TransformInvariantNMF(n_atoms=cfg['M'], atom_shape=tuple(cfg['A']), backend='hip', device=device,
-                                      path=path, init='device', process_group=pg, split=split, reduce=args.reduce)
-        model._initialize_matrices(V, keep_W=False)
+        model = TransformInvariantNMF(n_atoms=leg_cfg['M'], atom_shape=tuple(leg_cfg['A']), backend='hip', device=device,
+                                      path=path, init='device', process_group=pg, split=split, reduce=args.reduce,
+                                      sharded_input=pg is not None)
+        model._initialize_matrices(leg_V, keep_W=False)
         b = model._backend
-        if args.algorithm != 'full':
-            batches = b.minibatch_slices(batch_size)
+        if algorithm != 'full':
+            batches = b.minibatch_slices(batch)
             h_args = dict(sparsity=0., inhibition=args.inhibition, cross_inhibition=args.cross_inhibition)
-            epoch_fn = getattr(model, '_epoch_' + args.algorithm)
+            epoch_fn = getattr(model, '_epoch_' + algorithm)
             if args.eager:
                 model._use_schedules = False
             state = [None]
 
             def step():
-                state[0] = epoch_fn(state[0], batches, h_args, 0.8 if args.algorithm in ('asag', 'gsag') else 1.)
+                state[0] = epoch_fn(state[0], batches, h_args, 0.8 if algorithm in ('asag', 'gsag') else 1.)
         else:
             it_args = dict(sparsity=0., inhibition=args.inhibition, cross_inhibition=args.cross_inhibition)
             if args.eager:
@@ -417,12 +478,12 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize(device)
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         fence()
         b.start_timeline()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         fence()
         el = time.perf_counter() - t0
@@ -436,12 +497,104 @@ def main():
     nmf, elapsed, spans, paths = run_leg(args.path, group)
     be = nmf._backend
     energy = nmf._energy_function()     # collective when sharded; outside the timed region
+    last_family = be.last_path
+
+    # N > 1: evidence that the collective saw every rank, the latency of the one exchange step, and the further legs the
+    # north star words (strong scaling of config 3; configs 4 and 5 as sample-sharded Cyclic-MU) -- all measured here,
+    # none estimated.  Outside the headline's timed region.
+    dist_info, scaling_legs = None, {}
+    if group is not None:
+        ones = torch.ones(1, dtype=torch.float32, device=device)
+        dist.all_reduce(ones)           # every rank contributes 1: the sum is the number of ranks the collective reached
+        buf = torch.zeros(2 * cfg['M'] * cfg['C'] * int(np.prod(cfg['A'])), dtype=torch.float32, device=device)
+        for _ in range(5):
+            be._all_reduce(buf)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            be._all_reduce(buf)
+        torch.cuda.synchronize(device)
+        exch_us = (time.perf_counter() - t0) / 50 * 1e6
+        who = [None] * world
+        dist.all_gather_object(who, {'rank': rank, 'device': dev_index, 'name': torch.cuda.get_device_name(dev_index),
+                                     'pid': os.getpid()})
+        dist_info = {'backend': dist.get_backend(), 'is_rccl': dist.get_backend() == 'nccl',
+                     'rccl_ranks_seen': int(round(float(ones.item()))), 'world_size': world, 'reduce': args.reduce,
+                     'what': 'all-reduce (sum) of one 1.0 per rank over the process group the W gradient uses',
+                     'exchange_bytes': buf.numel() * 4, 'exchange_us_avg_of_50': exch_us, 'ranks': who}
+        del buf, ones
+        del nmf, be
+        nmf = be = None
+        torch.cuda.empty_cache()
+        from tnmf_amd import sharding
+        want = [] if args.legs in ('', 'none') or args.algorithm != 'full' else [x.strip() for x in args.legs.split(',')]
+        ls = args.leg_steps or min(args.steps, 20)
+
+        def leg_kernels(sp, pth):
+            return {nm: {'launches': len(ms), 'avg_ms': float(np.mean(ms)), 'family': pth.get(nm)} for nm, ms in sp.items()}
+
+        if 'strong' in want:
+            # STRONG scaling of the headline problem: cfg['N'] (256) GLOBAL samples, ceil(256 / N) per GPU (this rank takes
+            # them from the front of its own synthetic block), one W collective per iteration; beside it the same problem
+            # on ONE GPU without a process group (rank 0, its whole block), in the same run.
+            lo, hi = sharding.shard_bounds(cfg['N'], rank, world)
+            m_s, el_s, sp_s, pth_s = run_leg(args.path, group, leg_V=V[:hi - lo], algorithm='full', steps=ls)
+            n_glob_s = m_s._backend.n_samples
+            e_s = m_s._energy_function()
+            del m_s
+            torch.cuda.empty_cache()
+            el_1 = None
+            if rank == 0:
+                m_1, el_1, _sp1, _p1 = run_leg(args.path, None, leg_V=V, algorithm='full', steps=ls)
+                del m_1
+                torch.cuda.empty_cache()
+            dist.barrier()
+            scaling_legs['strong_scaling'] = {
+                'what': f'config 3 as ONE problem: {n_glob_s} global samples, {hi - lo} on rank 0, full-batch MU, one '
+                        f'collective of the W numerator / denominator per iteration',
+                'value': ls / el_s, 'unit': 'MU-iterations/sec (of the global problem)', 'scaling': 'strong',
+                'global_samples': n_glob_s, 'samples_on_rank0': hi - lo, 'steps': ls, 'ms_per_step': el_s / ls * 1e3,
+                'same_problem_on_one_gpu_same_run': {'value': ls / el_1, 'ms_per_step': el_1 / ls * 1e3,
+                                                     'where': 'rank 0 alone, no process group'} if el_1 else None,
+                'speedup_over_one_gpu': (el_1 / el_s) if el_1 else None,
+                'efficiency': (el_1 / el_s / world) if el_1 else None,
+                'kernels': leg_kernels(sp_s, pth_s), 'energy_after_run': e_s,
+            }
+        for leg, cid, local_batch in (('config4', 4, 64), ('config5', 5, 32)):
+            if leg not in want:
+                continue
+            # BASELINE configs[3] / configs[4]: mini-batch (Cyclic) MU, sample-sharded, ONE W collective per epoch; every
+            # GPU holds the per-GPU shard of the 8-GPU problem (at N = 8 this IS the configuration; at N < 8 the same
+            # shards, i.e. a problem of N / 8 of its size)
+            c = dict(CONFIGS[cid])
+            if args.samples:
+                c['N'] = args.samples
+                local_batch = max(1, args.samples // 2)
+            steps_c = args.leg_steps or (min(args.steps, 20) if cid == 4 else min(args.steps, 8))
+            Vc = synth_V_on_device(c, c['N'], 1234 + rank, device)
+            m_c, el_c, sp_c, pth_c = run_leg(args.path, group, leg_cfg=c, leg_V=Vc, algorithm='cyclic',
+                                             batch=local_batch * world, steps=steps_c, warmup=min(args.warmup, 2))
+            e_c = m_c._energy_function()
+            n_glob_c = m_c._backend.n_samples
+            del m_c, Vc
+            torch.cuda.empty_cache()
+            scaling_legs[leg + '_cyclic'] = {
+                'what': f'BASELINE.json configs[{cid - 1}] as worded: Cyclic-MU epochs (reference TransformInvariantNMF.py:'
+                        f'457-465), sample-sharded, {c["N"]} samples x {c["C"]} ch x {"x".join(map(str, c["D"]))} per GPU, '
+                        f'{c["M"]} atoms {"x".join(map(str, c["A"]))}, global batch {local_batch * world} = {local_batch} '
+                        f'per GPU, ONE collective of the W numerator / denominator per epoch',
+                'value': steps_c / el_c, 'unit': 'Cyclic-MU epochs/sec (of the global problem)',
+                'scaling': 'weak (per-GPU shard fixed)', 'global_samples': n_glob_c, 'samples_per_gpu': c['N'],
+                'global_batch': local_batch * world, 'steps': steps_c, 'ms_per_step': el_c / steps_c * 1e3,
+                'sample_epochs_per_sec': n_glob_c * steps_c / el_c,
+                'kernels': leg_kernels(sp_c, pth_c), 'energy_after_run': e_c,
+            }
 
     # Further legs (single GPU only): the same iterations from the same start on the other kernel families -- the
     # direct-vs-FFT crossover of BASELINE.json configs[4].
     variants = {}
     fams = set(paths.values())
-    main_family = ('hybrid' if 'fft' in fams and (fams & {'mfma', 'split', 'generic'}) else be.last_path)
+    main_family = ('hybrid' if 'fft' in fams and (fams & {'mfma', 'split', 'generic'}) else last_family)
     if 'split' in fams:
         main_family += '+split' if main_family != 'split' else ''
     if world == 1 and not args.no_fft_variant and k == 2:
@@ -528,6 +681,11 @@ def main():
                                   if args.algorithm == 'full' and not args.samples else (None, None))
             roof['rocprof_avg_launch_ms'] = prof_ms
             roof['rocprof_file'] = prof_file
+            # the two figures above that are READ from committed profiles (rocprof average, PMC traffic) were measured on
+            # the kernel sources of that round: False = the sources have changed since (figures stale), None = unknown
+            roof['rocprof_file_is_current'] = profile_is_current(prof_file)
+            roof['traffic_file'] = traffic['file'] if traffic else None
+            roof['traffic_file_is_current'] = profile_is_current(traffic['file']) if traffic else None
         else:
             # a whole epoch issued by one library call (tnmf_hip_run_schedule): no per-kernel events; the step is a chain
             # of tiny dependent launches, bound by launch latency, not by a roofline
@@ -568,12 +726,18 @@ def main():
                 'traffic_measured': traffic['iteration_bytes'] if traffic else None,
                 'traffic_over_bytes_alg': traffic['iteration_bytes'] / alg_bytes(cfg, n_local) if traffic else None,
                 'traffic_file': traffic['file'] if traffic else None,
+                'traffic_file_is_current': profile_is_current(traffic['file']) if traffic else None,
+                'sources_sha16': csrc_digest(),
             },
             'kernels': kernels,
             'roofline': roof,
             'roofline_by_kernel': rl,
         }
         line.update(variants)
+        line.update(scaling_legs)
+        if dist_info is not None:
+            line['distributed'] = dist_info
+            line['rccl_ranks_seen'] = dist_info['rccl_ranks_seen']
         if parity is not None:
             line['parity'] = parity
             line['energy_gap_vs_oracle'] = parity['energy_gap_vs_oracle']

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TNMF_HIP_ABI_VERSION 6
+#define TNMF_HIP_ABI_VERSION 7
 
 enum {
     TNMF_OK = 0,
@@ -83,6 +83,18 @@ enum { TNMF_PATH_AUTO = 0, TNMF_PATH_GENERIC = 1, TNMF_PATH_MFMA = 2, TNMF_PATH_
  * MFMA keeps every kernel on the exact f32-input MFMA (a k-ordered fmaf chain).  AUTO and HYBRID use the split H update
  * where it covers the shape (float32, 2-D, atoms up to 16 x 16) unless tnmf_hip_ctx_set_split(ctx, 0) turned it off. */
 int tnmf_hip_ctx_set_split(tnmf_hip_ctx *ctx, int enable);
+
+/* tnmf_hip_run_schedule walks the operation list of a TINY resident problem inside ONE persistent kernel whose workgroups
+ * meet at grid-wide barriers (generic.hip: k_schedule) -- which is only sound while every workgroup of the grid is
+ * resident.  The library sizes that grid with an occupancy query of the kernel's real footprint on this device; when not
+ * even that fits, or under mode 2 the runtime refuses the cooperative launch, the list is walked operation by operation
+ * instead (same arithmetic, more launches).  mode 0: never use the persistent kernel (a caller that shares the GPU with
+ * other processes -- CU masks, co-tenants -- should say so); 1 (default): plain launch of the occupancy-sized grid;
+ * 2: the same grid through hipLaunchCooperativeKernel.  (The reference has no counterpart: its schedules are Python
+ * loops, tnmf/TransformInvariantNMF.py:457-504.) */
+int tnmf_hip_ctx_set_persistent(tnmf_hip_ctx *ctx, int mode);
+/* 1 when the last tnmf_hip_run_schedule on this ctx ran as one persistent launch, 0 when it walked the list per operation. */
+int tnmf_hip_ctx_last_schedule_persistent(const tnmf_hip_ctx *ctx);
 
 int tnmf_hip_abi_version(void);
 /* Row stride (elements) this context would like H of `geom` to have: the shift width itself, or -- when the H update runs

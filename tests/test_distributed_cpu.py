@@ -46,8 +46,13 @@ def _spawn(fn, args_of_port, nprocs=2):
         try:
             mp.spawn(fn, args=args_of_port(_free_port()), nprocs=nprocs, join=True)
             return
-        except Exception:   # noqa: BLE001
-            if attempt:
+        except Exception as exc:   # noqa: BLE001
+            # only a lost race for the port is worth another port; anything else (an assertion inside a rank, a parity
+            # mismatch) is a genuine failure and surfaces on the first attempt
+            text = str(exc).lower()
+            port_race = any(k in text for k in ('address already in use', 'eaddrinuse', 'errno 98',
+                                                'connection refused', 'connection reset'))
+            if attempt or not port_race:
                 raise
 
 

@@ -14,9 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_fft_engine_matches_naive_dft(tmp_path):
     exe = str(tmp_path / 'fft_engine_check')
     src = os.path.join(ROOT, 'tests', 'native', 'fft_engine_check.cpp')
-    subprocess.run(['g++', '-O1', '-std=c++17', '-I', os.path.join(ROOT, 'tnmf_amd', 'csrc'), src, '-o', exe],
-                   check=True)
-    out = subprocess.run([exe], check=False, capture_output=True, text=True)
+    # AddressSanitizer + UndefinedBehaviorSanitizer on the host build (GPU sanitizers are not available
+    # on this pool): the stage functions index the tile with compile-time strides and digit-reversal tables -- an index
+    # one past the tile, a signed overflow in a twiddle index or a misaligned access aborts the run
+    subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+                    '-I', os.path.join(ROOT, 'tnmf_amd', 'csrc'), src, '-o', exe], check=True)
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
+    out = subprocess.run([exe], check=False, capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith('OK')
     # every transform length the library instantiates is covered

@@ -223,16 +223,29 @@ def test_f32_loop_parity_with_f64_oracle(N, C, D, M, A, path):
     np.random.seed(42)
     ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c').fit(V.astype(np.float64), n_iterations=5)
     assert relmax(nmf.W, ref.W) < 1e-5
+    assert abs(nmf._energy_function() - ref.energy()) / ref.energy() < 1e-5
     # north star: H within 1e-5 as well -- on every path that claims parity on H.  path='fft' in float32 does NOT: it is
     # the opt-in for callers who need W and the energy only (HIP_Backend docstring, include/tnmf_hip.h): float32
     # transforms carry an absolute error of ~1e-7 of the largest gradient entry into every entry, so activations whose
-    # gradients are tiny are relatively inexact (the reference's FFT backends share this in float32).  No bound on its H
-    # is asserted here -- only that it stays a valid factor; float64 transforms are held to 1e-10 elsewhere.
+    # gradients are tiny are relatively inexact (the reference's FFT backends share this in float32).  Its H is NOT held
+    # to the parity bar -- but it is held to a regression guard: the measured error is up to 2e-3 of max|H| on these shapes,
+    # and a broken fused FFT update or a stale spectrum cache (errors of tens of percent) must not pass as "a valid
+    # factor".  5e-3 is that guard, not a parity claim; float64 transforms are held to 1e-10 elsewhere.
     if path == 'fft':
         assert np.isfinite(nmf.H).all() and (nmf.H >= 0).all()
+        assert relmax(nmf.H, ref.H) < 5e-3
+        # ... and the fused update, which runs on the spectra the W half step left in the cache, computes what the
+        # family's own unfused gradient kernels compute from the same H on fresh storage (no cache): a stale spectrum
+        # would show here at any size of error
+        be = nmf._backend
+        H0 = nmf.H
+        nmf._update_H()
+        assert be.last_path == 'fft'
+        neg, pos = be.reconstruction_gradient_H(V, nmf._W, dev(H0, np.float32))
+        own = H0.astype(np.float64) * be.to_ndarray(neg) / (be.to_ndarray(pos).astype(np.float64) + 1e-9)
+        assert relmax(nmf.H, own) < 1e-5
     else:
         assert relmax(nmf.H, ref.H) < 1e-5
-    assert abs(nmf._energy_function() - ref.energy()) / ref.energy() < 1e-5
 
 
 BASELINE_SHAPES = [
@@ -331,9 +344,21 @@ def test_split_h_gradient_against_oracle(shape):
     assert err['split'] < 2 * err['mfma'] + 1e-7
 
 
-def _adversarial_case(kind):
-    """Operands the uniform-random cases never produce (parity is thin on dynamic range)."""
-    N, C, D, M, A = 2, 1, (48, 56), 32, (12, 12)
+ADVERSARIAL_GEOMETRIES = {
+    # id: (N, C, D, M, A, exact-f32 comparator family, lateral inhibition strength)
+    'a12_c1': (2, 1, (48, 56), 32, (12, 12), 'mfma', 0.),          # four-wave <12,3> instantiation (round 2's case)
+    'a16_c3': (2, 3, (40, 72), 40, (16, 16), 'mfma', 0.),          # eight-wave <16,4> workgroups, W image restaged per channel, partial atom tile
+    'a64_1d': (12, 2, (300,), 20, (64,), 'generic', 0.),           # 1-D instantiation <1,16>: tile rows = samples, partial sample block
+    'a12_extra': (2, 1, (48, 56), 32, (12, 12), 'mfma', 0.1),      # EXTRA-term epilogue: lateral inhibition in the fused kernel's denominator
+}
+
+
+def _adversarial_case(kind, geometry='a12_c1'):
+    """Operands the uniform-random cases never produce (parity is thin on dynamic range; r3: ... and on the
+    instantiations beyond 12 x 12 single-channel atoms)."""
+    N, C, D, M, A = ADVERSARIAL_GEOMETRIES[geometry][:5]
+    k = len(A)
+    axes = tuple(range(-k, 0))
     rng = np.random.default_rng(97)
     Hs = tuple(d + a - 1 for d, a in zip(D, A))
     V = rng.random((N, C) + D)
@@ -342,36 +367,62 @@ def _adversarial_case(kind):
     if kind == 'wide_V':
         # eight decades of dynamic range inside every window, exact zeros, a blank band
         V = 10.0 ** rng.uniform(-4, 4, size=V.shape) * (rng.random(V.shape) > 0.2)
-        V[:, :, 20:26, :] = 0.0
+        V[..., 20:26, :] = 0.0
+        if k == 1:
+            V[..., 100:130] = 0.0
     elif kind == 'tiny_W':
         # atoms with entries down to the smallest normal float32: whole rows, single taps, a whole atom; corners included
-        Wn[0, :, 3] = 1e-38
-        Wn[1, :, :, 5] = 3e-38
+        Wn[0, ..., 3] = 1e-38
+        Wn[1, :, ..., 5] = 3e-38
+        if k == 2:
+            Wn[0, :, 3] = 1e-38
+            Wn[1, :, :, 5] = 3e-38
         Wn[2] = 10.0 ** rng.uniform(-38, -30, size=Wn[2].shape)
-        Wn[3, :, -1, -1] = 1.2e-38
-        Wn[4, :, 0, 0] = 0.0
+        Wn[3].reshape(C, -1)[:, -1] = 1.2e-38
+        Wn[4].reshape(C, -1)[:, 0] = 0.0
         Wn[5] = 10.0 ** rng.uniform(-20, 0, size=Wn[5].shape)
     elif kind == 'sparse_H':
         # activations after 200 sparse MU iterations of the float64 oracle (most entries driven to ~0, a few large)
         orc.set_threads(orc.default_threads(cap=32))
         Vp = rng.random((N, C) + D) * (rng.random((N, C) + D) > 0.5)
         np.random.seed(5)
-        ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c').fit(Vp, n_iterations=200, sparsity_H=0.05)
+        ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c' if k == 2 else 'contract')
+        ref.fit(Vp, n_iterations=200 if k == 2 and C == 1 else 60, sparsity_H=0.05)
         return N, C, D, M, A, Vp, ref.W.copy(), ref.H.copy()
-    Wn /= Wn.sum(axis=(-2, -1), keepdims=True)
+    Wn /= Wn.sum(axis=axes, keepdims=True)
     return N, C, D, M, A, V, Wn, Hn
 
 
+def _row_padded(Hc):
+    """The values of a contiguous [N, M, Hy, Hx] tensor in storage whose rows are whole 128-byte lines (what initialize()
+    allocates under the default dispatch; the EXTRA-term epilogue of the split kernel runs on this layout only)."""
+    ld = -(-Hc.shape[3] // 32) * 32
+    store = torch.zeros(tuple(Hc.shape[:3]) + (ld,), dtype=Hc.dtype, device=Hc.device)
+    Hp = store[..., :Hc.shape[3]]
+    Hp.copy_(Hc)
+    return Hp
+
+
 @pytest.mark.parametrize('kind', ['wide_V', 'tiny_W', 'sparse_H'])
-def test_split_h_update_on_adversarial_operands(kind):
+@pytest.mark.parametrize('geometry', list(ADVERSARIAL_GEOMETRIES))
+def test_split_h_update_on_adversarial_operands(kind, geometry):
     """The 3 x bf16 split H gradient / fused update against the float64 C oracle on operands with a wide dynamic range:
-    never worse than twice the error of the exact f32 MFMA chain, measured against the output's maximum AND element by
-    element (all terms are non-negative: an element's own value is the scale of its rounding error)."""
-    N, C, D, M, A, V, Wn, Hn = _adversarial_case(kind)
+    never worse than twice the error of the exact f32 chain (f32-input MFMA; the generic f32 kernels for 1-D signals),
+    measured against the output's maximum AND element by element (all terms are non-negative: an element's own value is
+    the scale of its rounding error).  Every kind of instantiation of the split kernel: four-wave 12 x 12, eight-wave
+    16 x 16 with three channels, 1-D, and the EXTRA-term epilogue (lateral inhibition in the fused denominator)."""
+    import ctypes
+    from tnmf_amd import _lib
+    N, C, D, M, A, V, Wn, Hn = _adversarial_case(kind, geometry)
+    exact, inhibition = ADVERSARIAL_GEOMETRIES[geometry][5:]
+    k = len(A)
+    impl = 'c' if k == 2 else 'contract'
     # float32 images of the operands are THE operands: the oracle sees what the kernels see
     V, Wn, Hn = (np.asarray(x, dtype=np.float32).astype(np.float64) for x in (V, Wn, Hn))
-    on, op = orc.gradient_H(V, Wn, Hn, slice(None), 'c')
-    want_H = Hn * on / (op + 1e-9)
+    on, op = orc.gradient_H(V, Wn, Hn, slice(None), impl)
+    kernels = orc.inhibition_kernels(tuple(a - 1 for a in A))
+    E = inhibition * (orc.convolve_multi_1d(Hn, kernels, range(-k, 0)) - Hn) if inhibition > 0 else 0.
+    want_H = Hn * on / (op + E + 1e-9)
 
     def elementwise(got, want):
         want = np.asarray(want, dtype=np.float64)
@@ -379,16 +430,13 @@ def test_split_h_update_on_adversarial_operands(kind):
         return (np.abs(np.asarray(got, dtype=np.float64) - want) / (np.abs(want) + floor)).max()
 
     err = {}
-    for path in ('split', 'mfma'):
+    for path in ('split', exact):
         be = make_backend(V.astype(np.float32), A, M, path)
         W, H = dev(Wn, np.float32), dev(Hn, np.float32)
-        R = be.reconstruct(W, H)
         neg = torch.empty_like(H)
         pos = torch.empty_like(H)
-        from tnmf_amd import _lib
-        import ctypes
         # V correlation alone (pos also carries the f32 error of R): grad_H with the oracle's own R
-        Rd = dev(orc.reconstruct(Wn, Hn, 'c'), np.float32)
+        Rd = dev(orc.reconstruct(Wn, Hn, impl), np.float32)
         g = be._geom(N, M)
         _lib.check(be._lib.tnmf_hip_grad_H(be._ctx, ctypes.byref(g), ctypes.c_void_p(be._V_dev.data_ptr()),
                                            ctypes.c_void_p(Rd.data_ptr()), ctypes.c_void_p(W.data_ptr()),
@@ -396,14 +444,18 @@ def test_split_h_update_on_adversarial_operands(kind):
                                            ctypes.c_void_p(pos.data_ptr()), be._stream()), 'tnmf_hip_grad_H')
         assert be.last_path == path
         Hf = dev(Hn, np.float32)
-        be.fused_update_H(V, W, Hf, slice(None), sparsity=0., eps=1e-9)
+        if inhibition > 0:
+            Hf = _row_padded(Hf)
+            be.fused_update_H(V, W, Hf, slice(None), sparsity=0., eps=1e-9, inhibition=inhibition,
+                              inhibition_kernels=kernels)
+        else:
+            be.fused_update_H(V, W, Hf, slice(None), sparsity=0., eps=1e-9)
         assert be.last_path == path
         err[path] = dict(neg_max=relmax(be.to_ndarray(neg), on), neg_el=elementwise(be.to_ndarray(neg), on),
                          H_max=relmax(be.to_ndarray(Hf), want_H), H_el=elementwise(be.to_ndarray(Hf), want_H))
-        del R
-    print(kind, err)
-    for k in ('neg_max', 'neg_el', 'H_max', 'H_el'):
-        assert err['split'][k] <= 2 * err['mfma'][k] + 2.0 ** -22, (k, err)
+    print(kind, geometry, err)
+    for key in ('neg_max', 'neg_el', 'H_max', 'H_el'):
+        assert err['split'][key] <= 2 * err[exact][key] + 2.0 ** -22, (key, err)
     assert err['split']['neg_max'] < 2e-6 and err['split']['H_max'] < 2e-5
 
 

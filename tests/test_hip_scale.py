@@ -75,6 +75,79 @@ def test_config3_end_to_end_against_f64_oracle(N):
     assert dW < 1e-5 and dH < 1e-5 and gap < 1e-5, (dW, dH, gap)
 
 
+def test_config2_end_to_end_against_f64_oracle():
+    """BASELINE configs[1] at its full 64 samples (64 x 1 x 128 x 128, 16 atoms 9 x 9): 5 float32 iterations of the
+    default dispatch from the reference's seeded start against the float64 C oracle -- W, H and the energy within 1e-5."""
+    N, C, D, M, A = 64, 1, (128, 128), 16, (9, 9)
+    oracle_threads()
+    V = planted_V(N, C, D, M, A, seed=1234)
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=M, atom_shape=A, backend='hip', path='auto')
+    nmf.fit(V, n_iterations=5, progress_callback=lambda *_: True)
+    fams = nmf._backend.last_path
+    W, H, E = nmf.W, nmf.H, nmf._energy_function()
+    nmf._update_H()
+    assert fams == 'fft' and nmf._backend.last_path == 'split'     # the default dispatch at this size (hybrid + split)
+    del nmf
+    torch.cuda.empty_cache()
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c').fit(V.astype(np.float64), n_iterations=5)
+    dW, dH = relmax(W, ref.W), relmax(H, ref.H)
+    gap = abs(E - ref.energy()) / ref.energy()
+    print(f'config 2, N={N}: dW={dW:.2e} dH={dH:.2e} energy gap={gap:.2e}')
+    assert dW < 1e-5 and dH < 1e-5 and gap < 1e-5, (dW, dH, gap)
+
+
+def test_refit_across_dtypes_on_the_schedule_path():
+    """One model object fitted in float32 and then in float64 (and back) on a problem small enough for the persistent
+    schedule kernel (BASELINE config 1's geometry): the gradient accumulator the front end keeps between iterations
+    belongs to ONE fit -- a float32 buffer handed to a float64 run would be overrun by the library."""
+    rng = np.random.default_rng(3)
+    V = rng.random((10, 3, 60))
+    nmf = TransformInvariantNMF(n_atoms=8, atom_shape=(20,), backend='hip')
+    for dtype, tol in ((np.float32, 1e-5), (np.float64, 1e-10), (np.float32, 1e-5)):
+        np.random.seed(42)
+        nmf.fit(V.astype(dtype), n_iterations=4, progress_callback=lambda *_: True)
+        assert nmf._backend.prefers_schedule(nmf._H)
+        assert nmf._iteration_acc is not None and nmf._iteration_acc.dtype == nmf._W.dtype
+        np.random.seed(42)
+        ref = orc.OracleNMF(n_atoms=8, atom_shape=(20,)).fit(V.astype(dtype).astype(np.float64), n_iterations=4)
+        assert relmax(nmf.W, ref.W) < tol and relmax(nmf.H, ref.H) < tol
+    # the backend refuses an accumulator of another type outright
+    nmf.fit(V, n_iterations=1, progress_callback=lambda *_: True)
+    bad = torch.zeros((2,) + tuple(nmf._W.shape), dtype=torch.float32, device=nmf._W.device)
+    with pytest.raises(AssertionError):
+        nmf._backend.run_schedule(nmf._V, nmf._W, nmf._H, [('G', slice(None), 0., 1.), ('W',)], bad)
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float32, 1e-5), (np.float64, 1e-10)], ids=['f32', 'f64'])
+def test_persistent_schedule_kernel_is_a_checked_option(dtype, tol):
+    """The persistent schedule kernel (one launch per iteration of a tiny problem, grid-wide barriers) needs its whole
+    grid resident: the library sizes the grid by an occupancy query and falls back to the per-operation path when told to
+    (persistent=0: a caller that shares the GPU) or when the grid cannot be resident.  All three modes -- plain launch of
+    the occupancy-sized grid, cooperative launch, forced fallback -- compute the same factorisation (the same device
+    functions in the same order: bit-identical), and the library reports which way it went."""
+    rng = np.random.default_rng(8)
+    V = rng.random((10, 3, 60)).astype(dtype)     # BASELINE config 1's geometry
+    res = {}
+    for mode, want_persistent in ((1, True), (2, True), (0, False)):
+        np.random.seed(42)
+        nmf = TransformInvariantNMF(n_atoms=8, atom_shape=(20,), backend='hip', persistent=mode)
+        nmf.fit(V, n_iterations=6, progress_callback=lambda *_: True)
+        assert nmf._backend.prefers_schedule(nmf._H)
+        assert nmf._backend.last_schedule_persistent is want_persistent, mode
+        res[mode] = (nmf.W, nmf.H)
+        nmf.fit(V, algorithm=MiniBatchAlgorithm.ASG_MU, batch_size=3, n_epochs=2, progress_callback=lambda *_: True)
+        assert nmf._backend.last_schedule_persistent is want_persistent, mode
+        res[mode] += (nmf.W, nmf.H)
+    for mode in (2, 0):
+        for a, b in zip(res[1], res[mode]):
+            assert np.array_equal(a, b), mode
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=8, atom_shape=(20,)).fit(V.astype(np.float64), n_iterations=6)
+    assert relmax(res[0][0], ref.W) < tol and relmax(res[0][1], ref.H) < tol
+
+
 @pytest.mark.parametrize('C,D,M,A', [(3, (256, 256), 32, (12, 12)), (3, (512, 512), 64, (16, 16))],
                          ids=['config4_shard_geometry', 'config5_shard_geometry'])
 def test_cyclic_mu_f32_at_shard_geometry(C, D, M, A):
@@ -225,6 +298,57 @@ def test_two_ranks_in_one_process(mode, dtype, geom, tol):
     assert relmax(H2, single.H) < tol
     if dtype == np.float32:
         assert r0['family'] == 'fft'          # last call = energy -> reconstruct on the FFT family: hybrid was active
+
+
+@pytest.mark.parametrize('mode', ['batch', 'cyclic'])
+def test_ranks_bring_their_own_blocks(mode):
+    """HIP_Backend(sharded_input=True): every rank hands in ONLY its own samples (bench.py at N > 1: the global array
+    exists on no host).  Blocks of different length (5 + 2 of 7 samples): the ranks learn each other's counts through the
+    collective, the global sample range of each is its offset in rank order, the mini-batch plans pair up (the short rank
+    gets empty tail batches), and the factorisation equals the one of ranks that were handed the global array."""
+    C, D, M, A, N = 2, (20, 24), 5, (4, 5), 7
+    V = planted_V(N, C, D, M, A, seed=5, dtype=np.float64, density=0.05)
+    cuts = [(0, 5), (5, 7)]
+
+    def rank_body(rank, coll):
+        torch.cuda.set_device(0)
+        lo, hi = cuts[rank]
+        nmf = TransformInvariantNMF(n_atoms=M, atom_shape=A, backend='hip', process_group=coll, sharded_input=True)
+        plain_init = nmf._initialize_matrices
+
+        def seeded_init(V_, keep_W):
+            # the seeded start of the reference: every rank walks the GLOBAL stream and keeps its samples, which needs
+            # the counts of the ranks before it -- a collective, done BEFORE the lock that lets the ranks of this one
+            # process take turns at the global NumPy RNG
+            nmf._backend.exchange_sample_counts(V_.shape[0])
+            with _init_lock:
+                np.random.seed(42)
+                plain_init(V_, keep_W)
+
+        nmf._initialize_matrices = seeded_init
+        cb = lambda *_: True  # noqa: E731
+        if mode == 'batch':
+            nmf.fit(V[lo:hi], n_iterations=3, sparsity_H=0.05, progress_callback=cb)
+        else:
+            nmf.fit(V[lo:hi], algorithm=MiniBatchAlgorithm.Cyclic_MU, batch_size=2, n_epochs=3, sparsity_H=0.05,
+                    progress_callback=cb)
+        be = nmf._backend
+        return dict(W=nmf.W, H=nmf.H, E=nmf._energy_function(), shard=be.shard, n=be.n_samples,
+                    batches=be.minibatch_slices(2))
+
+    (r0, r1), _group = run_ranks(2, rank_body)
+    assert r0['shard'] == (0, 5) and r1['shard'] == (5, 7) and r0['n'] == r1['n'] == 7
+    assert len(r0['batches']) == len(r1['batches']) == 5          # local batch 1; rank 1's last three are empty
+    assert [b.stop - b.start for b in r1['batches']] == [1, 1, 0, 0, 0]
+    assert np.array_equal(r0['W'], r1['W']) and r0['E'] == r1['E']
+    np.random.seed(42)
+    ref = orc.OracleNMF(n_atoms=M, atom_shape=A, impl='c')
+    if mode == 'batch':
+        ref.fit(V, n_iterations=3, sparsity_H=0.05)
+    else:
+        ref.fit(V, algorithm=orc.MiniBatchAlgorithm.Cyclic_MU, batch_size=2, n_epochs=3, sparsity_H=0.05)
+    assert relmax(r0['W'], ref.W) < 1e-10 and relmax(np.concatenate([r0['H'], r1['H']]), ref.H) < 1e-10
+    assert abs(r0['E'] - ref.energy()) / ref.energy() < 1e-10
 
 
 @pytest.mark.parametrize('dtype', [np.float32, np.float64], ids=['f32', 'f64'])
@@ -433,6 +557,40 @@ def test_bench_two_rank_path_rehearsal(tmp_path):
     assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0 and line['scaling'] == 'weak'
     assert line['config']['global_samples'] == 16 and line['config']['algorithm'] == 'cyclic'
     assert 'sample-sharded x2' in line['config']['parallelism']
+    assert line['rccl_ranks_seen'] == 2 and line['distributed']['backend'] == 'gloo'
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """The form the driver's SCALE run takes: plain `python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment.
+    bench.py starts the two ranks itself as CHILD processes (torch.distributed.run) before it touches the GPU and relays
+    rank 0's line; the line carries the weak-scaling headline, the strong-scaling leg of the same configuration (global
+    sample count fixed, half per rank, with the one-GPU run of the same problem beside it), the Cyclic-MU legs on the shards
+    of configs 4 and 5 (one collective per epoch), and the number of ranks the collective reached.  Two ranks share the one
+    GPU of the test box, so the collective is gloo (TNMF_BENCH_DIST_BACKEND) and no number here is a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['TNMF_BENCH_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--config', '2',
+           '--samples', '8']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['config']['global_samples'] == 16 and line['config']['samples_per_gpu'] == 8
+    assert line['rccl_ranks_seen'] == 2 and line['distributed']['world_size'] == 2
+    assert sorted(r['rank'] for r in line['distributed']['ranks']) == [0, 1]
+    assert len({r['pid'] for r in line['distributed']['ranks']}) == 2
+    st = line['strong_scaling']
+    assert st['scaling'] == 'strong' and st['global_samples'] == 8 and st['samples_on_rank0'] == 4 and st['value'] > 0
+    assert st['same_problem_on_one_gpu_same_run']['value'] > 0 and st['speedup_over_one_gpu'] > 0
+    for leg, n_per_gpu in (('config4_cyclic', 8), ('config5_cyclic', 8)):
+        assert line[leg]['global_samples'] == 2 * n_per_gpu and line[leg]['value'] > 0
+        assert np.isfinite(line[leg]['energy_after_run'])
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -193,7 +193,8 @@ class TransformInvariantNMF:
         run = self._scheduler(h_args)
         if run is not None and getattr(self._backend, 'prefers_schedule', lambda *_: False)(self._H):
             ops = ([('H', sliceNone)] if update_H else []) + ([('G', sliceNone, 0., 1.), ('W',)] if update_W else [])
-            if self._iteration_acc is None or self._iteration_acc.shape[1:] != self._W.shape:
+            acc = self._iteration_acc
+            if acc is None or acc.shape[1:] != self._W.shape or acc.dtype != self._W.dtype or acc.device != self._W.device:
                 self._iteration_acc = self._backend.new_gradient_accumulator(self._W)
             run(self._V, self._W, self._H, ops, self._iteration_acc, sparsity=h_args['sparsity'], eps=self.eps)
             return
@@ -204,6 +205,7 @@ class TransformInvariantNMF:
 
     def _initialize_matrices(self, V: np.ndarray, keep_W: bool):
         self._V = V
+        self._iteration_acc = None    # (sized and typed for the W of ONE fit: a refit may change dtype or device)
         self._W, self._H = self._backend.initialize(self._V, self.atom_shape, self.n_atoms,
                                                     self._W if keep_W else None, self._axes_W_normalization)
 

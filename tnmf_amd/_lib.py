@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libtnmf_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/tnmf_hip.h declares
 EXPORTS = (
@@ -20,7 +20,8 @@ EXPORTS = (
     'tnmf_hip_grad_H', 'tnmf_hip_grad_W', 'tnmf_hip_mu_update', 'tnmf_hip_normalize_W', 'tnmf_hip_energy',
     'tnmf_hip_convolve_multi_1d', 'tnmf_hip_update_H', 'tnmf_hip_grad_W_fused', 'tnmf_hip_apply_W',
     'tnmf_hip_pad_H', 'tnmf_hip_fold_H', 'tnmf_hip_ctx_set_cache', 'tnmf_hip_ctx_invalidate',
-    'tnmf_hip_ctx_set_split', 'tnmf_hip_ctx_h_row_stride', 'tnmf_hip_ctx_bind',
+    'tnmf_hip_ctx_set_split', 'tnmf_hip_ctx_h_row_stride', 'tnmf_hip_ctx_bind', 'tnmf_hip_ctx_set_persistent',
+    'tnmf_hip_ctx_last_schedule_persistent',
     'tnmf_hip_ctx_cache_counters', 'tnmf_hip_sum_parts',
     'tnmf_hip_update_H_ex', 'tnmf_hip_run_schedule', 'tnmf_hip_axpby', 'tnmf_hip_convolve_axis',
 )
@@ -82,6 +83,9 @@ def load() -> ctypes.CDLL:
     lib.tnmf_hip_ctx_set_path.argtypes = [vp, ci]
     lib.tnmf_hip_ctx_set_cache.argtypes = [vp, ci]
     lib.tnmf_hip_ctx_set_split.argtypes = [vp, ci]
+    lib.tnmf_hip_ctx_set_persistent.argtypes = [vp, ci]
+    lib.tnmf_hip_ctx_last_schedule_persistent.argtypes = [vp]
+    lib.tnmf_hip_ctx_last_schedule_persistent.restype = ci
     lib.tnmf_hip_ctx_h_row_stride.argtypes = [vp, gp, ctypes.POINTER(ci)]
     lib.tnmf_hip_ctx_invalidate.argtypes = [vp]
     lib.tnmf_hip_ctx_bind.argtypes = [vp, gp, vp, vp]

@@ -79,10 +79,20 @@ class HIP_Backend(Backend):
            ``'ordered'``: all-gather of the ranks' [neg | pos] buffers, then their sum in rank order by a library kernel --
            bit-identical on every rank and from run to run.  The buffers are 37-393 KB: either way the
            exchange is latency-bound.
+    persistent : how tnmf_hip_run_schedule may run a TINY resident problem (BASELINE config 1): ``1`` (default) one
+           persistent kernel per call whose grid is sized by an occupancy query -- its grid-wide barriers need every
+           workgroup resident, which the library checks instead of assuming; ``2`` the same through
+           hipLaunchCooperativeKernel; ``0`` never (walk the list operation by operation: say so when the GPU is shared
+           with other processes).  Where the persistent grid does not fit the library falls back by itself.
+    sharded_input : ``False`` (default): every rank passes the GLOBAL ``V`` to ``fit`` / ``initialize`` and keeps its
+           block (sharding.shard_bounds).  ``True``: every rank passes ONLY ITS OWN samples (the global array never
+           exists on any host: 3.2 GB x 8 at BASELINE config 5); the ranks' blocks follow each other in rank order and may
+           differ in length (one all-reduce of the per-rank counts at initialize).
     """
 
     def __init__(self, reconstruction_mode: str = 'valid', device=None, path: str = 'auto', init: str = 'reference',
-                 process_group=None, split: bool = True, reduce: str = 'all_reduce'):
+                 process_group=None, split: bool = True, reduce: str = 'all_reduce', sharded_input: bool = False,
+                 persistent: int = 1):
         if reconstruction_mode not in _lib.MODES:
             raise ValueError(f'Unsupported reconstruction mode "{reconstruction_mode}". '
                              f'Please choose "valid", "full", "circular", or "reflect".')
@@ -100,10 +110,14 @@ class HIP_Backend(Backend):
             raise ValueError(f'reduce must be "all_reduce" or "ordered", not {reduce!r}')
         self._init_mode = init
         self._reduce = reduce
+        self._sharded_input = bool(sharded_input)
+        self._counts = None         # samples per rank (sharded_input: as handed in; else sharding.shard_bounds)
+        self._counts_pending = None
         self._ctx = ctypes.c_void_p()
         _lib.check(self._lib.tnmf_hip_ctx_create(self._device.index, ctypes.byref(self._ctx)), 'tnmf_hip_ctx_create')
         _lib.check(self._lib.tnmf_hip_ctx_set_path(self._ctx, _lib.PATHS[path]), 'tnmf_hip_ctx_set_path')
         _lib.check(self._lib.tnmf_hip_ctx_set_split(self._ctx, 1 if split else 0), 'tnmf_hip_ctx_set_split')
+        _lib.check(self._lib.tnmf_hip_ctx_set_persistent(self._ctx, int(persistent)), 'tnmf_hip_ctx_set_persistent')
         # FFT family: the library may reuse the row spectra of H between the fused half steps (it updated H itself);
         # every other entry point below declares H as possibly changed first (_foreign_H).
         _lib.check(self._lib.tnmf_hip_ctx_set_cache(self._ctx, 1 if reconstruction_mode == 'valid' else 0),
@@ -152,6 +166,11 @@ class HIP_Backend(Backend):
     @property
     def last_path(self) -> str:
         return self._lib.tnmf_hip_ctx_last_path(self._ctx).decode()
+
+    @property
+    def last_schedule_persistent(self) -> bool:
+        """Whether the last run_schedule call ran as ONE persistent kernel launch (else: operation by operation)."""
+        return bool(self._lib.tnmf_hip_ctx_last_schedule_persistent(self._ctx))
 
     @property
     def cache_counters(self) -> dict:
@@ -287,7 +306,7 @@ class HIP_Backend(Backend):
         and all ranks get the same number of batches (possibly empty at the tail) so their all-reduces pair up.
         Without a group this is the reference's sequential split (TransformInvariantNMF.py:29-37).
         """
-        return sharding.local_minibatches(self.n_samples, self._rank, self._world, batch_size)
+        return sharding.local_minibatches(self.n_samples, self._rank, self._world, batch_size, counts=self._counts)
 
     @property
     def _padded_shape(self) -> Tuple[int, ...]:
@@ -334,17 +353,45 @@ class HIP_Backend(Backend):
             sharding.all_reduce_sum(t, self._group)
 
     # -- set-up ---------------------------------------------------------------------------------------------
+    def exchange_sample_counts(self, n_local: int):
+        """sharded_input: the ranks' sample counts in rank order (one small all-reduce).  initialize() does this itself;
+        a caller that has to serialise the seeded draw of several ranks inside one process (the tests) does it first --
+        the result is kept for the next initialize() with that many samples."""
+        counts = torch.zeros(self._world, dtype=torch.float64, device=self._device)
+        counts[self._rank] = n_local
+        saved, self._reduce = self._reduce, 'all_reduce'
+        try:
+            self._all_reduce(counts)
+        finally:
+            self._reduce = saved
+        self._counts_pending = [int(round(c)) for c in counts.tolist()]
+        return self._counts_pending
+
     def _initialize_matrices(self, V: np.ndarray, atom_shape, n_atoms: int, W=None, axes_W_normalization=None):
         if V.dtype not in _DTYPES:
             raise TypeError(f'the hip backend computes in float32 or float64, V has dtype {V.dtype}')
         if len(atom_shape) not in (1, 2, 3):   # (3: volumes, on the direct kernels of tnmf_amd/csrc/volume.hip)
             raise NotImplementedError('the hip backend supports 1, 2 or 3 shift dimensions')
         self._torch_dtype, self._dtype_code = _DTYPES[V.dtype]
-        N = self.n_samples
         self._foreign_H()
-        n0, n1 = self._shard = sharding.shard_bounds(N, self._rank, self._world)
+        if self._sharded_input and self._world > 1:
+            # V is this rank's block already: the ranks tell each other their sample counts (one small all-reduce)
+            pending, self._counts_pending = self._counts_pending, None
+            if pending is None or pending[self._rank] != V.shape[0]:
+                pending = self.exchange_sample_counts(V.shape[0])
+                self._counts_pending = None
+            self._counts = pending
+            self.n_samples = N = sum(self._counts)
+            n0 = sum(self._counts[:self._rank])
+            n0, n1 = self._shard = (n0, n0 + self._counts[self._rank])
+            V_local = V
+        else:
+            N = self.n_samples
+            n0, n1 = self._shard = sharding.shard_bounds(N, self._rank, self._world)
+            self._counts = None
+            V_local = V[n0:n1]
         with torch.cuda.device(self._device):
-            self._V_dev = torch.as_tensor(np.ascontiguousarray(V[n0:n1])).to(self._device)
+            self._V_dev = torch.as_tensor(np.ascontiguousarray(V_local)).to(self._device)
             ld = ctypes.c_int(0)
             if self._mode == 0 and len(atom_shape) == 2 and n1 > n0:
                 _lib.check(self._lib.tnmf_hip_ctx_h_row_stride(self._ctx, ctypes.byref(self._geom(n1 - n0, n_atoms)),
@@ -644,6 +691,7 @@ class HIP_Backend(Backend):
         ld = self._row_stride(H)
         assert ld is not None and H.shape[0] == self.n_local_samples
         assert acc.is_contiguous() and tuple(acc.shape) == (2,) + tuple(W.shape)
+        assert acc.dtype == W.dtype and acc.device == W.device   # (the library writes 2 * |W| elements of W's type)
         arr = (_lib.Op * max(1, len(ops)))()
         for i, op in enumerate(ops):
             if op[0] == 'W':
@@ -667,6 +715,7 @@ class HIP_Backend(Backend):
         """W = W * neg / (pos + eps), then normalise over the atom axes (TransformInvariantNMF.py:232-238)."""
         self._check_W(W)
         assert negpos.is_contiguous() and tuple(negpos.shape) == (2,) + tuple(W.shape)
+        assert negpos.dtype == W.dtype and negpos.device == W.device
         g = self._geom(0, W.shape[0])
         with self._timed('apply_W'):
             _lib.check(self._lib.tnmf_hip_apply_W(self._ctx, ctypes.byref(g), _ptr(W), _ptr(negpos), float(eps),

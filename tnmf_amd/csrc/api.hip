@@ -624,6 +624,15 @@ int tnmf_hip_ctx_set_split(tnmf_hip_ctx *ctx, int enable) {
     return TNMF_OK;
 }
 
+int tnmf_hip_ctx_set_persistent(tnmf_hip_ctx *ctx, int mode) {
+    if (!ctx) return TNMF_E_NULL;
+    if (mode < 0 || mode > 2) return TNMF_E_UNSUPPORTED;
+    ctx->persistent = mode;
+    return TNMF_OK;
+}
+
+int tnmf_hip_ctx_last_schedule_persistent(const tnmf_hip_ctx *ctx) { return ctx && ctx->last_schedule_persistent ? 1 : 0; }
+
 int tnmf_hip_ctx_set_cache(tnmf_hip_ctx *ctx, int enable) {
     if (!ctx) return TNMF_E_NULL;
     ctx->fft.cache_enabled = enable != 0;
@@ -940,6 +949,10 @@ int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
     // gradient of one batch behind them
     int nmax = 1;
     for (int i = 0; i < n_ops; ++i) {
+        // (checked for the whole list before anything runs: the persistent kernel walks it on the device)
+        if (ops[i].kind != TNMF_OP_UPDATE_H && ops[i].kind != TNMF_OP_GRAD_W && ops[i].kind != TNMF_OP_APPLY_W)
+            return TNMF_E_UNSUPPORTED;
+        if (ops[i].kind == TNMF_OP_APPLY_W) continue;
         if (ops[i].n0 < 0 || ops[i].n1 < ops[i].n0 || ops[i].n1 > g.N) return TNMF_E_GEOM;
         if (ops[i].n1 - ops[i].n0 > nmax) nmax = ops[i].n1 - ops[i].n0;
     }
@@ -952,7 +965,7 @@ int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
     // the launches they replace: 28.5 ms per ASG epoch against 26.7 ms.)
     (void)nmax;
     const bool tiny = (size_t)g.N * g.M * g.Hy * g.Hx <= ((size_t)1 << 18);
-    if (n_ops > 0 && tiny && (ctx->path == TNMF_PATH_AUTO || ctx->path == TNMF_PATH_GENERIC) &&
+    if (n_ops > 0 && tiny && ctx->persistent != 0 && (ctx->path == TNMF_PATH_AUTO || ctx->path == TNMF_PATH_GENERIC) &&
         generic_schedule_fits(ctx, g, dtype)) {
         const int P = generic_schedule_chunks(ctx, g);
         const size_t r_bytes = R_scratch ? 0 : align_up((size_t)g.N * vs, 256);
@@ -985,9 +998,16 @@ int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
         }
         fft_invalidate(ctx);   // H and W change under the family's caches
         ctx->last_path = "generic";
-        return generic_run_schedule(ctx, g, dtype, V, W_inout, H_inout, Rs, acc, partials, P, ops_dev, n_ops, reg, eps,
-                                    counter, s);
+        const int rc = generic_run_schedule(ctx, g, dtype, V, W_inout, H_inout, Rs, acc, partials, P, ops_dev, n_ops, reg,
+                                            eps, counter, s);
+        // TNMF_E_UNSUPPORTED: the grid cannot be co-resident on this device right now (occupancy query / cooperative
+        // launch refused) -- nothing was launched; the list is walked operation by operation below
+        if (rc != TNMF_E_UNSUPPORTED) {
+            ctx->last_schedule_persistent = rc == TNMF_OK;
+            return rc;
+        }
     }
+    ctx->last_schedule_persistent = false;
     Geo gmax = g;
     gmax.N = nmax;
     const Scratch scm = plan_scratch(ctx, gmax, dtype);

@@ -74,6 +74,10 @@ struct tnmf_hip_ctx {
     size_t ops_cap[kOpSlots] = {0, 0, 0, 0};
     hipEvent_t ops_done[kOpSlots] = {nullptr, nullptr, nullptr, nullptr};
     int ops_next = 0;
+    // persistent schedule kernel (generic.hip: k_schedule): 0 = never, 1 = plain launch of a grid sized by the occupancy
+    // query, 2 = the same grid through hipLaunchCooperativeKernel (tnmf_hip_ctx_set_persistent)
+    int persistent = 1;
+    bool last_schedule_persistent = false;   // the last tnmf_hip_run_schedule ran as ONE launch of k_schedule
     FftState fft;
 };
 

@@ -1069,6 +1069,24 @@ bool generic_schedule_fits(const tnmf_hip_ctx *, const Geo &g, int dtype) {
     return lds <= 64 * 1024;
 }
 
+// Workgroups of k_schedule that are resident AT ONCE on this device, capped at min(CUs, 128): the kernel's grid.  Its
+// barrier spins until every workgroup of the grid has arrived, so a workgroup that is not resident (waiting for a slot a
+// spinning workgroup holds) would hang the launch: residency is a checked precondition (occupancy query with the
+// kernel's real register / LDS footprint), not an assumption about "one workgroup of <= 64 KB per CU".  0: not even one.
+static int schedule_grid(const tnmf_hip_ctx *ctx, int dtype, size_t lds) {
+    int per_cu = 0;
+    const hipError_t e = dtype == 0
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_schedule<float>, kBlock, lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_schedule<double>, kBlock, lds);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    const long resident = (long)per_cu * ctx->num_cu;
+    const int want = ctx->num_cu < 128 ? ctx->num_cu : 128;
+    return (int)(resident < want ? resident : want);
+}
+
 int generic_schedule_chunks(const tnmf_hip_ctx *ctx, const Geo &g) {
     // split of the pixel sum of the W gradient: enough (chunk, atom, channel) blocks for the grid, no more
     const int grid = ctx->num_cu < 128 ? ctx->num_cu : 128;
@@ -1097,10 +1115,25 @@ int generic_run_schedule(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void 
     a.eps = eps;
     a.counter = counter;
     const size_t lds = dtype == 0 ? schedule_lds<float>(g, a.tR, a.tW, a.tH) : schedule_lds<double>(g, a.tR, a.tW, a.tH);
-    if (lds > 64 * 1024) return TNMF_E_UNSUPPORTED;
-    // one workgroup per CU at most (4 waves, <= 64 KB of LDS): the whole grid is resident at once, which the barrier needs
-    const int grid = ctx->num_cu < 128 ? ctx->num_cu : 128;
+    if (lds > 64 * 1024 || ctx->persistent == 0) return TNMF_E_UNSUPPORTED;
+    // the whole grid must be resident at once (the barrier): as many workgroups as the occupancy query says fit, at most
+    // one per CU and 128 (the kernel's loops stride by gridDim.x: any grid size computes the same thing)
+    const int grid = schedule_grid(ctx, dtype, lds);
+    if (grid < 1) return TNMF_E_UNSUPPORTED;   // (nothing launched, nothing written: the caller walks the list per operation)
     TNMF_HIP_TRY(hipMemsetAsync(counter, 0, 64 * sizeof(unsigned), s));
+    if (ctx->persistent == 2) {
+        // cooperative launch: the runtime refuses a grid it cannot make co-resident instead of starting it
+        void *params[] = {&a};
+        const hipError_t e = hipLaunchCooperativeKernel(
+            dtype == 0 ? (const void *)k_schedule<float> : (const void *)k_schedule<double>, dim3(grid), dim3(kBlock), params,
+            (unsigned)lds, s);
+        if (e == hipErrorCooperativeLaunchTooLarge || e == hipErrorNotSupported) {
+            (void)hipGetLastError();
+            return TNMF_E_UNSUPPORTED;
+        }
+        if (e != hipSuccess) return (int)e;
+        return TNMF_OK;
+    }
     if (dtype == 0)
         hipLaunchKernelGGL(k_schedule<float>, dim3(grid), dim3(kBlock), lds, s, a);
     else

@@ -19,18 +19,25 @@ def shard_bounds(n_samples: int, rank: int, world: int) -> Tuple[int, int]:
     return min(n_samples, rank * per), min(n_samples, (rank + 1) * per)
 
 
-def local_minibatches(n_samples: int, rank: int, world: int, batch_size: Optional[int]) -> List[slice]:
+def local_minibatches(n_samples: int, rank: int, world: int, batch_size: Optional[int],
+                      counts: Optional[Sequence[int]] = None) -> List[slice]:
     """
     Sequential mini-batches in the rank's LOCAL sample coordinates.  Global batch j is the union of every rank's
     local batch j; each rank contributes ceil(batch_size / world) of its own samples and all ranks get the same
     number of batches (possibly empty ones at the tail) so that their all-reduces pair up.
     world == 1 reproduces the reference's sequential split (tnmf/TransformInvariantNMF.py:29-37).
+    `counts`: samples per rank when the ranks brought their own blocks (HIP_Backend(sharded_input=True)) instead of the
+    even split of shard_bounds.
     """
     if batch_size is None:
         return [sliceNone]
-    n0, n1 = shard_bounds(n_samples, rank, world)
-    n_local = n1 - n0
-    largest = -(-n_samples // world)
+    if counts is not None:
+        assert len(counts) == world and sum(counts) == n_samples
+        n_local, largest = int(counts[rank]), int(max(counts))
+    else:
+        n0, n1 = shard_bounds(n_samples, rank, world)
+        n_local = n1 - n0
+        largest = -(-n_samples // world)
     b = max(1, -(-int(batch_size) // world))
     return [slice(min(lo, n_local), min(lo + b, n_local)) for lo in range(0, largest, b)]
 

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], int(sys.argv[2])
 src = os.path.join(ROOT, 'gpurun_out', 'final_' + tag)
 pre = os.path.join(ROOT, 'profiles', 'r%02d_' % rnd)
+if os.path.exists(src + '/sources.sha16'):   # digest of the kernel sources the batch ran on (bench.py: *_is_current)
+    shutil.copy(src + '/sources.sha16', pre + 'sources.sha16')
 for f in sorted(glob.glob(src + '/traffic_config*.json') + glob.glob(src + '/rocprof_kernel_stats_config*.csv') +
                 glob.glob(src + '/bench_*.json')):
     dst = pre + os.path.basename(f)

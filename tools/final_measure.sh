@@ -9,6 +9,7 @@ configs=${2:-"3 2 4 5"}
 out=$R/gpurun_out/final_$tag
 mkdir -p $out
 cd $R
+python3 -c "import bench; print(bench.csrc_digest())" > $out/sources.sha16 || exit 1   # what these profiles are measured on
 Q="--no-cpu-baseline --no-fft-variant --no-parity"
 if [ "$3" != "nobench" ]; then
   timeout -k 10 500 python3 bench.py > $out/bench_n1.json 2> $out/bench_n1.err || { echo "bench failed"; tail -3 $out/bench_n1.err; exit 1; }
