@@ -125,8 +125,8 @@ def test_persistent_schedule_kernel_is_a_checked_option(dtype, tol):
     """The persistent schedule kernel (one launch per iteration of a tiny problem, grid-wide barriers) needs its whole
     grid resident: the library sizes the grid by an occupancy query and falls back to the per-operation path when told to
     (persistent=0: a caller that shares the GPU) or when the grid cannot be resident.  All three modes -- plain launch of
-    the occupancy-sized grid, cooperative launch, forced fallback -- compute the same factorisation (the same device
-    functions in the same order: bit-identical), and the library reports which way it went."""
+    the occupancy-sized grid, cooperative launch, forced fallback -- compute the same factorisation (the two launch
+    flavours of the persistent kernel bit for bit), and the library reports which way it went."""
     rng = np.random.default_rng(8)
     V = rng.random((10, 3, 60)).astype(dtype)     # BASELINE config 1's geometry
     res = {}
@@ -140,9 +140,12 @@ def test_persistent_schedule_kernel_is_a_checked_option(dtype, tol):
         nmf.fit(V, algorithm=MiniBatchAlgorithm.ASG_MU, batch_size=3, n_epochs=2, progress_callback=lambda *_: True)
         assert nmf._backend.last_schedule_persistent is want_persistent, mode
         res[mode] += (nmf.W, nmf.H)
-    for mode in (2, 0):
-        for a, b in zip(res[1], res[mode]):
-            assert np.array_equal(a, b), mode
+    for a, b in zip(res[1], res[2]):
+        assert np.array_equal(a, b)               # the same kernel, launched cooperatively: the same bits
+    for a, b in zip(res[1], res[0]):
+        # the per-operation path may split the pixel sum of the W gradient differently (and picks its kernels per
+        # operation): the same arithmetic up to the order of additions
+        assert relmax(a, b) < (1e-12 if dtype == np.float64 else 2e-6)
     np.random.seed(42)
     ref = orc.OracleNMF(n_atoms=8, atom_shape=(20,)).fit(V.astype(np.float64), n_iterations=6)
     assert relmax(res[0][0], ref.W) < tol and relmax(res[0][1], ref.H) < tol

@@ -614,6 +614,7 @@ int tnmf_hip_ctx_reserve(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom) {
 int tnmf_hip_ctx_set_path(tnmf_hip_ctx *ctx, int path) {
     if (!ctx) return TNMF_E_NULL;
     if (path < TNMF_PATH_AUTO || path > TNMF_PATH_SPLIT) return TNMF_E_UNSUPPORTED;
+    if (path != ctx->path) fft_invalidate(ctx);   // (the FFT family's workspace layout follows the path: column lengths)
     ctx->path = path;
     return TNMF_OK;
 }

@@ -22,12 +22,15 @@ namespace {
 // contraction's work.  Along y (column transforms) 270 shortens the full spectra by 6 %; its column kernels run 480
 // threads (4320 tile elements: 9 per thread).  540 stays out of the y list: its 16-column H-gradient tile would be 18
 // elements per thread at 480 threads -- measured 41.8 ms against 28.7 ms for the pure-FFT H update of the config-5 shard.
+// That kernel only runs under TNMF_PATH_FFT: under every other dispatch (AUTO / HYBRID: the H update is a direct kernel)
+// the column direction takes 540 as well (`tall`): the full spectra of H at the config-5 shard (527 shifts) are 6 %
+// shorter -- they are written once and read three times per iteration -- and so are the contractions that stream them.
 const int kLensY[] = {32, 48, 64, 96, 144, 192, 270, 288, 384, 576};
 const int kLensX[] = {32, 48, 64, 96, 144, 192, 270, 288, 384, 540, 576};
 constexpr int kMixMaxGroups = 128;   // partial-sum slots of the mixed W-gradient kernel (Gn / Gp)
 
-int pick_len(int h, int dtype, bool along_x) {
-    if (along_x) {
+int pick_len(int h, int dtype, bool along_x, bool tall = false) {
+    if (along_x || tall) {
         for (int L : kLensX)
             if (L >= h && (dtype == 0 || L <= 288)) return L;
         return 0;
@@ -36,6 +39,9 @@ int pick_len(int h, int dtype, bool along_x) {
         if (L >= h && (dtype == 0 || L <= 288)) return L;
     return 0;
 }
+
+// the column direction may take the x-only lengths whenever the FFT family's own H-gradient kernel cannot be asked for
+bool tall_columns(const tnmf_hip_ctx *ctx) { return ctx->path != TNMF_PATH_FFT; }
 
 fft_run_fn lookup(int L) {
     switch (L) {
@@ -77,8 +83,8 @@ void sample_groups(const Geo &g, int tiles, int *ngroups, int *nper) {
     *ngroups = cdiv(g.N > 0 ? g.N : 1, *nper);
 }
 
-bool make_layout(const Geo &gfull, const Geo &g, int dtype, Lay *l) {
-    l->Ly = pick_len(g.Hy, dtype, false);
+bool make_layout(const tnmf_hip_ctx *ctx, const Geo &gfull, const Geo &g, int dtype, Lay *l) {
+    l->Ly = pick_len(g.Hy, dtype, false, tall_columns(ctx));
     l->Lx = pick_len(g.Hx, dtype, true);
     if (!l->Ly || !l->Lx) return false;
     l->rowf = lookup(l->Lx);
@@ -417,7 +423,7 @@ int prepare(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void *H, const voi
         }
     }
     const bool in_binding = c->sl.cached || c->sl.v_cached;
-    if (!make_layout(in_binding ? f.geo : g, g, dtype, &c->l)) return TNMF_E_UNSUPPORTED;
+    if (!make_layout(ctx, in_binding ? f.geo : g, g, dtype, &c->l)) return TNMF_E_UNSUPPORTED;
     CHECK(ensure_ws(ctx, window ? c->l.total : c->l.total_no_window));
     const Lay &l = c->l;
     const size_t n0 = (size_t)c->sl.n0;
@@ -564,7 +570,7 @@ int fft_reserve(tnmf_hip_ctx *ctx, const Geo &g, int dtype, bool with_window) {
     ctx->fft.failed_bytes = 0;   // an explicit request: try again even if this size was refused before
     const FftState &f = ctx->fft;
     const bool in_binding = f.bound && f.dtype == dtype && same_shape(f.geo, g) && f.geo.N >= g.N;
-    if (!fft_has(g, dtype) || !make_layout(in_binding ? f.geo : g, g, dtype, &l)) return TNMF_E_UNSUPPORTED;
+    if (!fft_has(g, dtype) || !make_layout(ctx, in_binding ? f.geo : g, g, dtype, &l)) return TNMF_E_UNSUPPORTED;
     return ensure_ws(ctx, with_window ? l.total : l.total_no_window);
 }
 

@@ -393,6 +393,28 @@ __device__ __forceinline__ void store_col_tile_rows(const cplx<T> *x, cplx<T> *d
     }
 }
 
+// (tile, plane) of a workgroup of the plain column kernels, grid (tiles, planes).  The long transforms take 8-column
+// tiles: 64-byte HALF lines of the row spectra, the other half of every line belonging to the neighbouring tile -- and the
+// hardware deals consecutive workgroups round-robin to the eight XCDs, so the two halves were fetched by two different L2s:
+// FETCH_SIZE of k_fft_cols_fwd<float, 576, 512> read 2.6x the stream at the config-5 shard, and the calibration on exactly
+// this shape (tools/probes/fetch_calib_cols.hip, profiles/r04_fetch_calib_cols.txt) shows the doubling is real and that it
+// vanishes -- 1.00x, and 1291 -> 845 us for the bare reads -- when every XCD walks a CONTIGUOUS chunk of the (tile fastest)
+// order: the neighbour then runs on the same XCD at about the same time and finds the line in its L2.  16-column tiles
+// are whole lines and keep the natural order.
+template <int CT>
+__device__ __forceinline__ void col_block(int &tile, long &plane) {
+    if constexpr (CT >= 16) {
+        tile = blockIdx.x;
+        plane = blockIdx.y;
+    } else {
+        long lin = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long whole = (long)gridDim.x * gridDim.y / 8 * 8;
+        if (lin < whole) lin = (lin & 7) * (whole / 8) + (lin >> 3);
+        tile = (int)(lin % gridDim.x);
+        plane = lin / gridDim.x;
+    }
+}
+
 // kFftColsFwd: src0 row spectra [planes][rows][KXP] -> dst0 full spectra [planes][L][KXP]
 template <typename T, int L, int NT>
 __global__ __launch_bounds__(NT) void k_fft_cols_fwd(FftArgs a) {
@@ -401,8 +423,10 @@ __global__ __launch_bounds__(NT) void k_fft_cols_fwd(FftArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
     cplx<T> *tw = x + L * (ColTile<L, WIDE>::v + 1);
-    const int tid = threadIdx.x, kx0 = blockIdx.x * ColTile<L, WIDE>::v;
-    const long plane = blockIdx.y;
+    int tile;
+    long plane;
+    col_block<ColTile<L, WIDE>::v>(tile, plane);
+    const int tid = threadIdx.x, kx0 = tile * ColTile<L, WIDE>::v;
     make_twiddles<T, L>(tw, tid, NT);
     load_col_tile<T, L, NT, WIDE>(x, static_cast<const cplx<T> *>(a.src0) + plane * ((long)a.rows * a.KXP), a.rows, a.KXP,
                             a.KX, kx0, tid);
@@ -420,8 +444,10 @@ __global__ __launch_bounds__(NT) void k_fft_cols_inv(FftArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
     cplx<T> *tw = x + L * (ColTile<L, WIDE>::v + 1);
-    const int tid = threadIdx.x, kx0 = blockIdx.x * ColTile<L, WIDE>::v;
-    const long plane = blockIdx.y;
+    int tile;
+    long plane;
+    col_block<ColTile<L, WIDE>::v>(tile, plane);
+    const int tid = threadIdx.x, kx0 = tile * ColTile<L, WIDE>::v;
     make_twiddles<T, L>(tw, tid, NT);
     load_col_tile<T, L, NT, WIDE>(x, static_cast<const cplx<T> *>(a.src0) + plane * ((long)L * a.KXP), L, a.KXP, a.KX, kx0,
                             tid);
@@ -460,6 +486,67 @@ __device__ __forceinline__ void commit_col_tile(cplx<T> *x, const cplx<T> *pre, 
         cplx<T> v = pre[e];
         if (y >= rows || kx0 + col >= KX) v = {0, 0};
         x[y * (ColTile<L, WIDE>::v + 1) + col] = v;
+    }
+}
+
+// kFftColsFwd, persistent form.  The plain kernel above is one tile per workgroup: load (every thread waits for its 9
+// values), three stages, store -- with nothing of the next tile in flight; the two or three workgroups of a CU overlap
+// each other's phases only by chance, and the launch ran at 2.9 TB/s of its streams at the config-5 shard where a copy
+// runs at 4.7.  Here a workgroup WALKS tiles: the next tile's values are fetched into registers (unconditional loads on
+// clamped addresses, see fetch_col) before the current tile is transformed, and committed to LDS once the current one
+// has been stored.  The walk keeps the XCD-contiguous order of col_block: XCD x owns the contiguous chunk x of the
+// (tile fastest) item order, and its workgroups take consecutive items of it side by side, so the two 8-column tiles
+// that share 128-byte lines still meet in one L2 at about the same time.
+template <typename T, int L, int NT>
+__global__ __launch_bounds__(NT) void k_fft_cols_fwd_p(FftArgs a, int tiles, long items) {
+    using P = FftPlanFor<T, L>;
+    constexpr bool WIDE = false;
+    constexpr int CT = ColTile<L, WIDE>::v, E = L * CT / NT;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
+    cplx<T> *tw = x + L * (CT + 1);
+    const int tid = threadIdx.x;
+    make_twiddles<T, L>(tw, tid, NT);
+    // items of this workgroup: first, step, end (exclusive)
+    long it, step, end;
+    if ((gridDim.x & 7) == 0 && items >= 8) {
+        const long per = (items + 7) / 8, xcd = blockIdx.x & 7;
+        it = xcd * per + (blockIdx.x >> 3);
+        step = gridDim.x >> 3;
+        end = (xcd + 1) * per < items ? (xcd + 1) * per : items;
+    } else {
+        it = blockIdx.x;
+        step = gridDim.x;
+        end = items;
+    }
+    if (it >= end) return;
+    const cplx<T> *src = static_cast<const cplx<T> *>(a.src0);
+    cplx<T> *dst = static_cast<cplx<T> *>(a.dst0);
+    const long tplane = (long)a.rows * a.KXP, splane = (long)L * a.KXP;
+    cplx<T> pre[E];
+    int kx0 = (int)(it % tiles) * CT;
+    long plane = it / tiles;
+    ColLane ln = col_lane<L, NT, WIDE>(a.KX, kx0, tid);
+    fetch_col<T, L, NT, WIDE>(pre, src + plane * tplane, ln, a.rows, a.KXP);
+    for (;;) {
+        commit_col_tile<T, L, NT, WIDE>(x, pre, a.rows, a.KX, kx0, tid);
+        __syncthreads();
+        const int kx0_cur = kx0;
+        const long plane_cur = plane;
+        const long nxt = it + step;
+        const bool more = nxt < end;
+        {   // unconditional (hipcc loses count of loads inside branches and drains): the last round re-reads its own tile
+            const long nx = more ? nxt : it;
+            kx0 = (int)(nx % tiles) * CT;
+            plane = nx / tiles;
+            ln = col_lane<L, NT, WIDE>(a.KX, kx0, tid);
+            fetch_col<T, L, NT, WIDE>(pre, src + plane * tplane, ln, a.rows, a.KXP);
+        }
+        tile_fwd<T, P, CT, (CT + 1), NT>(x, tw, tid);
+        store_col_tile_rows<T, L, NT, WIDE>(x, dst + plane_cur * splane, L, 0, a.KXP, a.KX, kx0_cur, tid);
+        if (!more) break;
+        it = nxt;
+        __syncthreads();   // every thread has read its part of the tile: the next one may be committed
     }
 }
 
@@ -740,8 +827,40 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
             TNMF_FFT_LAUNCH((k_fft_rows_mu<T, L, NBM, NTM>), mgrid, NTM,
                             (size_t)L * (NBM + 1) * sizeof(cplx<T>) + tw_bytes + stash);
         }
-        case kFftColsFwd:
+        case kFftColsFwd: {
+#ifdef TNMF_FFT_COLS_PLAIN
             TNMF_FFT_LAUNCH((k_fft_cols_fwd<T, L, NTC>), dim3(tiles, (unsigned)a->planes), NTC, col_lds);
+#else
+            // persistent form: as many workgroups as are resident at once (LDS: 160 KB per CU), a multiple of 8
+            static const int ncu = [] {
+                int dev = 0, n = 256;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                    (void)hipGetLastError();
+                return n > 0 ? n : 256;
+            }();
+            const long items = (long)tiles * a->planes;
+            int per_cu = (int)((160 * 1024) / col_lds);
+            if (per_cu > 2048 / NTC) per_cu = 2048 / NTC;
+            if (per_cu < 1) per_cu = 1;
+            long nb = (long)ncu * per_cu / 8 * 8;
+            if (nb > items) nb = items;
+            if (nb < 1) return TNMF_OK;
+            do {
+                static std::atomic<unsigned> attr_done{0};
+                int dev_ = 0;
+                if (hipGetDevice(&dev_) != hipSuccess) return (int)hipGetLastError();
+                const unsigned bit_ = 1u << (dev_ & 31);
+                if ((col_lds) > 64 * 1024 && !(attr_done.load(std::memory_order_acquire) & bit_)) {
+                    const int _rc = set_lds_limit((k_fft_cols_fwd_p<T, L, NTC>), (col_lds));
+                    if (_rc != TNMF_OK) return _rc;
+                    attr_done.fetch_or(bit_, std::memory_order_release);
+                }
+                hipLaunchKernelGGL((k_fft_cols_fwd_p<T, L, NTC>), dim3((unsigned)nb), dim3(NTC), col_lds, s, *a, (int)tiles, items);
+                TNMF_LAUNCH_CHECK();
+                return TNMF_OK;
+            } while (0);
+#endif
+        }
         case kFftColsInv:
             TNMF_FFT_LAUNCH((k_fft_cols_inv<T, L, NTC>), dim3(tiles, (unsigned)a->planes), NTC, col_lds);
         case kFftContractR: {
