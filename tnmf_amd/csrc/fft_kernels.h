@@ -489,67 +489,6 @@ __device__ __forceinline__ void commit_col_tile(cplx<T> *x, const cplx<T> *pre, 
     }
 }
 
-// kFftColsFwd, persistent form.  The plain kernel above is one tile per workgroup: load (every thread waits for its 9
-// values), three stages, store -- with nothing of the next tile in flight; the two or three workgroups of a CU overlap
-// each other's phases only by chance, and the launch ran at 2.9 TB/s of its streams at the config-5 shard where a copy
-// runs at 4.7.  Here a workgroup WALKS tiles: the next tile's values are fetched into registers (unconditional loads on
-// clamped addresses, see fetch_col) before the current tile is transformed, and committed to LDS once the current one
-// has been stored.  The walk keeps the XCD-contiguous order of col_block: XCD x owns the contiguous chunk x of the
-// (tile fastest) item order, and its workgroups take consecutive items of it side by side, so the two 8-column tiles
-// that share 128-byte lines still meet in one L2 at about the same time.
-template <typename T, int L, int NT>
-__global__ __launch_bounds__(NT) void k_fft_cols_fwd_p(FftArgs a, int tiles, long items) {
-    using P = FftPlanFor<T, L>;
-    constexpr bool WIDE = false;
-    constexpr int CT = ColTile<L, WIDE>::v, E = L * CT / NT;
-    extern __shared__ __align__(16) unsigned char smem[];
-    cplx<T> *x = reinterpret_cast<cplx<T> *>(smem);
-    cplx<T> *tw = x + L * (CT + 1);
-    const int tid = threadIdx.x;
-    make_twiddles<T, L>(tw, tid, NT);
-    // items of this workgroup: first, step, end (exclusive)
-    long it, step, end;
-    if ((gridDim.x & 7) == 0 && items >= 8) {
-        const long per = (items + 7) / 8, xcd = blockIdx.x & 7;
-        it = xcd * per + (blockIdx.x >> 3);
-        step = gridDim.x >> 3;
-        end = (xcd + 1) * per < items ? (xcd + 1) * per : items;
-    } else {
-        it = blockIdx.x;
-        step = gridDim.x;
-        end = items;
-    }
-    if (it >= end) return;
-    const cplx<T> *src = static_cast<const cplx<T> *>(a.src0);
-    cplx<T> *dst = static_cast<cplx<T> *>(a.dst0);
-    const long tplane = (long)a.rows * a.KXP, splane = (long)L * a.KXP;
-    cplx<T> pre[E];
-    int kx0 = (int)(it % tiles) * CT;
-    long plane = it / tiles;
-    ColLane ln = col_lane<L, NT, WIDE>(a.KX, kx0, tid);
-    fetch_col<T, L, NT, WIDE>(pre, src + plane * tplane, ln, a.rows, a.KXP);
-    for (;;) {
-        commit_col_tile<T, L, NT, WIDE>(x, pre, a.rows, a.KX, kx0, tid);
-        __syncthreads();
-        const int kx0_cur = kx0;
-        const long plane_cur = plane;
-        const long nxt = it + step;
-        const bool more = nxt < end;
-        {   // unconditional (hipcc loses count of loads inside branches and drains): the last round re-reads its own tile
-            const long nx = more ? nxt : it;
-            kx0 = (int)(nx % tiles) * CT;
-            plane = nx / tiles;
-            ln = col_lane<L, NT, WIDE>(a.KX, kx0, tid);
-            fetch_col<T, L, NT, WIDE>(pre, src + plane * tplane, ln, a.rows, a.KXP);
-        }
-        tile_fwd<T, P, CT, (CT + 1), NT>(x, tw, tid);
-        store_col_tile_rows<T, L, NT, WIDE>(x, dst + plane_cur * splane, L, 0, a.KXP, a.KX, kx0_cur, tid);
-        if (!more) break;
-        it = nxt;
-        __syncthreads();   // every thread has read its part of the tile: the next one may be committed
-    }
-}
-
 // kFftContractR: R^[n,c,f] = sum_m H^[n,m,f] W^[m,c,f]   (reconstruct, NumPy.py:122-132 in the frequency domain)
 //   src0 = row spectra of H [N*M][Hy][KXP], src1 = W spectra [M*C][L][KXP], dst0 = R spectra [N*C][L][KXP]
 //   grid (N, tiles, channel groups of CG).  The next atom's tile is fetched while the current one is transformed.
@@ -827,40 +766,10 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
             TNMF_FFT_LAUNCH((k_fft_rows_mu<T, L, NBM, NTM>), mgrid, NTM,
                             (size_t)L * (NBM + 1) * sizeof(cplx<T>) + tw_bytes + stash);
         }
-        case kFftColsFwd: {
-#ifdef TNMF_FFT_COLS_PLAIN
+        case kFftColsFwd:
+            // (a persistent form -- a workgroup walks tiles with the next tile prefetched into registers -- was measured in
+            // round 4 and not kept: no gain over three one-tile workgroups per CU, profiles/r04_ab_cols_persistent_vs_plain.txt)
             TNMF_FFT_LAUNCH((k_fft_cols_fwd<T, L, NTC>), dim3(tiles, (unsigned)a->planes), NTC, col_lds);
-#else
-            // persistent form: as many workgroups as are resident at once (LDS: 160 KB per CU), a multiple of 8
-            static const int ncu = [] {
-                int dev = 0, n = 256;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-                    (void)hipGetLastError();
-                return n > 0 ? n : 256;
-            }();
-            const long items = (long)tiles * a->planes;
-            int per_cu = (int)((160 * 1024) / col_lds);
-            if (per_cu > 2048 / NTC) per_cu = 2048 / NTC;
-            if (per_cu < 1) per_cu = 1;
-            long nb = (long)ncu * per_cu / 8 * 8;
-            if (nb > items) nb = items;
-            if (nb < 1) return TNMF_OK;
-            do {
-                static std::atomic<unsigned> attr_done{0};
-                int dev_ = 0;
-                if (hipGetDevice(&dev_) != hipSuccess) return (int)hipGetLastError();
-                const unsigned bit_ = 1u << (dev_ & 31);
-                if ((col_lds) > 64 * 1024 && !(attr_done.load(std::memory_order_acquire) & bit_)) {
-                    const int _rc = set_lds_limit((k_fft_cols_fwd_p<T, L, NTC>), (col_lds));
-                    if (_rc != TNMF_OK) return _rc;
-                    attr_done.fetch_or(bit_, std::memory_order_release);
-                }
-                hipLaunchKernelGGL((k_fft_cols_fwd_p<T, L, NTC>), dim3((unsigned)nb), dim3(NTC), col_lds, s, *a, (int)tiles, items);
-                TNMF_LAUNCH_CHECK();
-                return TNMF_OK;
-            } while (0);
-#endif
-        }
         case kFftColsInv:
             TNMF_FFT_LAUNCH((k_fft_cols_inv<T, L, NTC>), dim3(tiles, (unsigned)a->planes), NTC, col_lds);
         case kFftContractR: {
