@@ -389,8 +389,18 @@ def main():
             tiles = -(-n_local // 8) * -(-Hs[0] // 32) * -(-cfg['M'] // 32) * cfg['C']
             return launch_scale * tiles * 4 * kb * 4 * 6 * (2.0 * 32 * 32 * 16)
         ay, ax = cfg['A']
-        kb = (((ay + 1) // 2) * ((ax + 3) // 4) + 1) // 2
+        # the instantiation that runs the shape (split.hip: the covering (atom rows, runs of four taps) pair with the
+        # fewest k blocks); 12 x 12 and 16 x 16 run on v_mfma_f32_16x16x32_bf16 (k blocks of 32 = eight (row, run) slots)
+        cover = [(a, r) for a, r in ((12, 3), (9, 3), (16, 4), (7, 2), (8, 2), (5, 2)) if a >= ay and 4 * r >= ax]
+        if not cover:
+            return None
+        ai, ri = min(cover, key=lambda ar: (((ar[0] + 1) // 2) * ar[1] + 1) // 2)
         tiles = n_local * -(-Hs[0] // 8) * -(-Hs[1] // 32) * -(-cfg['M'] // 32) * cfg['C']
+        if (ai, ri) in ((12, 3), (16, 4)):
+            kb32 = -(-ai * ri // 8)
+            # per wave (two rows of the tile) and k block: 8 groups (row, V | R, pixel half) x 2 atom halves x 6 products
+            return launch_scale * tiles * 4 * kb32 * 8 * 12 * (2.0 * 16 * 16 * 32)
+        kb = (((ai + 1) // 2) * ri + 1) // 2
         return launch_scale * tiles * 4 * kb * 4 * 6 * (2.0 * 32 * 32 * 16)
 
     def group_roofline(name, avg_ms, paths):
@@ -413,7 +423,7 @@ def main():
              'traffic': kbytes}
         if fam == 'split':
             peak = PEAK_BF16_TFLOPS / 6.0
-            ex = split_executed_flops()
+            ex = split_executed_flops() or 0.0
             r.update({'bound': 'mfma', 'achieved': r['alg_tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                       'frac': r['alg_tflops'] / peak,
                       'peak_basis': 'dense bf16 MFMA peak (2500 TFLOP/s) / 6 bf16 products per float32-grade product '

@@ -964,6 +964,8 @@ int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
     // the per-operation path below: measured on the reference's mini-batch geometry, 768 x 1 x 32 x 32 with batch_size 3,
     // the grid barriers of the persistent kernel -- agent-scope release / acquire across eight L2s -- cost as much as
     // the launches they replace: 28.5 ms per ASG epoch against 26.7 ms.)
+    // (Round 4 built an XCD-local flavour of that kernel for exactly that case -- the workgroups of ONE XCD, barriers without
+    // the L2 write-back: 22.3 ms per ASG epoch against 12.0 on the per-operation path below, profiles/r04_xcd_local_schedule_kernel.txt.)
     (void)nmax;
     const bool tiny = (size_t)g.N * g.M * g.Hy * g.Hx <= ((size_t)1 << 18);
     if (n_ops > 0 && tiny && ctx->persistent != 0 && (ctx->path == TNMF_PATH_AUTO || ctx->path == TNMF_PATH_GENERIC) &&
@@ -972,7 +974,7 @@ int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
         const size_t r_bytes = R_scratch ? 0 : align_up((size_t)g.N * vs, 256);
         const size_t p_bytes = align_up((size_t)P * wn * 2 * sizeof(double), 256);
         const size_t o_bytes = align_up((size_t)n_ops * sizeof(tnmf_hip_op), 256);
-        CHECK(ensure_scratch(ctx, r_bytes + p_bytes + o_bytes + 512));
+        CHECK(ensure_scratch(ctx, r_bytes + p_bytes + o_bytes + 1024));
         void *Rs = R_scratch ? R_scratch : static_cast<void *>(ws_at(ctx, 0));
         double *partials = reinterpret_cast<double *>(ws_at(ctx, r_bytes));
         tnmf_hip_op *ops_dev = reinterpret_cast<tnmf_hip_op *>(ws_at(ctx, r_bytes + p_bytes));

@@ -175,15 +175,14 @@ __global__ __launch_bounds__(kBlock) void k_reconstruct(Geo g, Tile t, const T *
 constexpr int kSmallTY = 2, kSmallTX = 32, kSmallQ = 4;
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_reconstruct_small(Geo g, int tiles_y, int tiles_x, const T *__restrict__ W,
-                                                              const T *__restrict__ H, T *__restrict__ R) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void reconstruct_small_block(const Geo &g, int tiles_y, int tiles_x, unsigned bid,
+                                                        const T *__restrict__ W, const T *__restrict__ H,
+                                                        T *__restrict__ R, unsigned char *smem_raw) {
     const int SH = kSmallTY + g.Ay - 1, SW = kSmallTX + g.Ax - 1, nel = SH * SW, nA = g.Ay * g.Ax;
     const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T *Hs = reinterpret_cast<T *>(smem_raw) + (size_t)q * (nel + nA);
     T *Ws = Hs + nel;
     T *red = reinterpret_cast<T *>(smem_raw) + (size_t)kSmallQ * (nel + nA);   // [kSmallQ][64]
-    unsigned bid = blockIdx.x;
     const int txi = bid % tiles_x;
     bid /= tiles_x;
     const int tyi = bid % tiles_y;
@@ -250,6 +249,22 @@ __global__ __launch_bounds__(kBlock) void k_reconstruct_small(Geo g, int tiles_y
         const int y = y0 + ty, x = x0 + tx;
         if (y < g.Dy && x < g.Dx) R[(((size_t)n * g.C + c) * g.Dy + y) * g.Dx + x] = tot;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reconstruct_small(Geo g, int tiles_y, int tiles_x, const T *__restrict__ W,
+                                                              const T *__restrict__ H, T *__restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    reconstruct_small_block<T>(g, tiles_y, tiles_x, blockIdx.x, W, H, R, smem_raw);
+}
+
+// whether a reconstruct call of this geometry takes the small-call form (launch_reconstruct and the schedule kernel agree)
+template <typename T>
+inline bool reconstruct_is_small(const Geo &g, const Tile &t, size_t *lds_small) {
+    const size_t blocks = (size_t)g.N * g.C * t.tiles_y * t.tiles_x;
+    *lds_small = ((size_t)kSmallQ * ((size_t)(kSmallTY + g.Ay - 1) * (kSmallTX + g.Ax - 1) + (size_t)g.Ay * g.Ax) +
+                  (size_t)kSmallQ * 64) * sizeof(T);
+    return blocks < 64 && g.M >= kSmallQ && g.Dy > 1 && *lds_small <= 64 * 1024;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -599,7 +614,8 @@ struct SchedArgs {
     const tnmf_hip_op *ops;
     int n_ops, P;
     double reg, eps;
-    unsigned *counter;      // zeroed before the launch
+    unsigned *counter;      // zeroed before the launch: [0] arrivals, [32] generation
+    int small_max;          // reconstruct of slices of up to this many samples takes the small-call form (0: never)
 };
 
 // counter[0]: arrivals (monotonic), counter[32]: generation flag on a line of its own.  The last workgroup to arrive
@@ -608,6 +624,7 @@ struct SchedArgs {
 // release) before it issues the agent-scope release, and its agent-scope acquire invalidates the CU's vector cache for
 // all four waves.
 __device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned &target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (every wave: its own stores have left the CU before wave 0 releases)
     __syncthreads();
     target += gridDim.x;
     if (threadIdx.x < 64) {
@@ -626,6 +643,12 @@ __device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned &target
     __syncthreads();
 }
 
+// (An XCD-LOCAL flavour -- the workgroups of ONE XCD, elected through the hardware XCC id register, walk the list and
+// meet at barriers without the agent-scope release, for the small batches of a large problem -- was built and measured in
+// round 4 and not kept: 22.3 ms per ASG epoch on the reference's mini-batch geometry against 12.0 on the per-operation path;
+// its barriers alone cost 5 us each.  profiles/r04_xcd_local_schedule_kernel.txt.)
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_schedule(SchedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -634,6 +657,8 @@ __global__ __launch_bounds__(kBlock) void k_schedule(SchedArgs a) {
     const size_t vs = (size_t)g.C * g.Dy * g.Dx, hs = (size_t)g.M * g.Hy * g.Hs;
     T *W = static_cast<T *>(a.W), *acc = static_cast<T *>(a.acc);
     unsigned target = 0;
+    const unsigned wg = blockIdx.x, nwg = gridDim.x;
+    auto barrier = [&]() { grid_barrier(a.counter, target); };
     for (int i = 0; i < a.n_ops; ++i) {
         const tnmf_hip_op op = a.ops[i];
         Geo gs = g;
@@ -642,28 +667,37 @@ __global__ __launch_bounds__(kBlock) void k_schedule(SchedArgs a) {
         T *Hb = static_cast<T *>(a.H) + (size_t)op.n0 * hs;
         T *Rb = static_cast<T *>(a.R) + (size_t)op.n0 * vs;
         if (op.kind == TNMF_OP_UPDATE_H || op.kind == TNMF_OP_GRAD_W) {
-            const unsigned nb = (unsigned)(gs.N * g.C * a.tR.tiles_y * a.tR.tiles_x);
-            for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) reconstruct_block<T>(gs, a.tR, b, W, Hb, Rb, smem_raw);
-            grid_barrier(a.counter, target);
+            if (gs.N <= a.small_max) {   // (the small-call form, under launch_reconstruct's own condition)
+                const int sty = cdiv_dev(g.Dy, kSmallTY), stx = cdiv_dev(g.Dx, kSmallTX);
+                const unsigned nb = (unsigned)(gs.N * g.C * sty * stx);
+                for (unsigned b = wg; b < nb; b += nwg) {
+                    reconstruct_small_block<T>(gs, sty, stx, b, W, Hb, Rb, smem_raw);
+                    __syncthreads();   // (the block function leaves its LDS tiles in use by wave 0's final sum)
+                }
+            } else {
+                const unsigned nb = (unsigned)(gs.N * g.C * a.tR.tiles_y * a.tR.tiles_x);
+                for (unsigned b = wg; b < nb; b += nwg) reconstruct_block<T>(gs, a.tR, b, W, Hb, Rb, smem_raw);
+            }
+            barrier();
         }
         if (op.kind == TNMF_OP_UPDATE_H) {
             const unsigned nb = (unsigned)(gs.N * g.M * a.tW.tiles_y * a.tW.tiles_x);
-            for (unsigned b = blockIdx.x; b < nb; b += gridDim.x)
+            for (unsigned b = wg; b < nb; b += nwg)
                 corr_W_block<T, true>(gs, a.tW, b, Vb, Rb, W, Hb, (T *)nullptr, (T *)nullptr, (T)a.reg, (const T *)nullptr,
                                       smem_raw);
-            grid_barrier(a.counter, target);
+            barrier();
         } else if (op.kind == TNMF_OP_GRAD_W) {
             const int items = gs.N * a.tH.tiles_y * a.tH.tiles_x;
             const int P = items < a.P ? (items > 0 ? items : 1) : a.P;
-            for (unsigned b = blockIdx.x; b < (unsigned)(P * MC); b += gridDim.x)
+            for (unsigned b = wg; b < (unsigned)(P * MC); b += nwg)
                 corr_H_block<T>(gs, a.tH, P, (int)(b % P), (int)(b / P), Vb, Rb, Hb, a.partials, smem_raw);
-            grid_barrier(a.counter, target);
+            barrier();
             // fixed-order sum of the partials (double), flip to the reference's orientation, blend into the accumulator:
             // one workgroup per (m, c) row -- and when the W update follows immediately (ASG / ASAG: every batch), that
             // workgroup applies it to its row on the spot: one barrier less per batch step
             const int total = MC * nA;
             const bool apply_now = i + 1 < a.n_ops && a.ops[i + 1].kind == TNMF_OP_APPLY_W;
-            for (unsigned r = blockIdx.x; r < (unsigned)MC; r += gridDim.x) {
+            for (unsigned r = wg; r < (unsigned)MC; r += nwg) {
                 for (int sh = threadIdx.x; sh < nA; sh += kBlock) {
                     const int e = (int)r * nA + sh;
                     double sn = 0.0, sp = 0.0;
@@ -681,13 +715,13 @@ __global__ __launch_bounds__(kBlock) void k_schedule(SchedArgs a) {
                 if (apply_now) apply_normalize_row<T, true>(nA, r, W, acc, acc + (size_t)MC * nA, (T)a.eps);
             }
             if (apply_now) ++i;    // (the W update has been done)
-            grid_barrier(a.counter, target);
+            barrier();
         } else if (op.kind == TNMF_OP_APPLY_W) {
-            for (unsigned r = blockIdx.x; r < (unsigned)MC; r += gridDim.x) {
+            for (unsigned r = wg; r < (unsigned)MC; r += nwg) {
                 __syncthreads();   // (the row reduction's shared words are reused row after row)
                 apply_normalize_row<T, true>(nA, r, W, acc, acc + (size_t)MC * nA, (T)a.eps);
             }
-            grid_barrier(a.counter, target);
+            barrier();
         }
     }
 }
@@ -755,17 +789,14 @@ int launch_reconstruct(const Geo &g, const void *W, const void *H, void *R, hipS
     if (lds > 64 * 1024) return TNMF_E_UNSUPPORTED;
     const size_t blocks = (size_t)g.N * g.C * t.tiles_y * t.tiles_x;
     if (blocks > 0x7fffffffull) return TNMF_E_GEOM;
-    if (blocks < 64 && g.M >= kSmallQ && g.Dy > 1) {
+    size_t lds_small = 0;
+    if (reconstruct_is_small<T>(g, t, &lds_small)) {
         // a small call (a mini-batch of a few samples): four waves per tile of 2 x 32 pixels, each on its own atoms
         const int tiles_y = cdiv(g.Dy, kSmallTY), tiles_x = cdiv(g.Dx, kSmallTX);
-        const size_t lds_small = ((size_t)kSmallQ * ((size_t)(kSmallTY + g.Ay - 1) * (kSmallTX + g.Ax - 1) + (size_t)g.Ay * g.Ax) +
-                                  (size_t)kSmallQ * 64) * sizeof(T);
-        if (lds_small <= 64 * 1024) {
-            hipLaunchKernelGGL(k_reconstruct_small<T>, dim3((unsigned)((size_t)g.N * g.C * tiles_y * tiles_x)), dim3(kBlock),
-                               lds_small, s, g, tiles_y, tiles_x, (const T *)W, (const T *)H, (T *)R);
-            TNMF_LAUNCH_CHECK();
-            return TNMF_OK;
-        }
+        hipLaunchKernelGGL(k_reconstruct_small<T>, dim3((unsigned)((size_t)g.N * g.C * tiles_y * tiles_x)), dim3(kBlock),
+                           lds_small, s, g, tiles_y, tiles_x, (const T *)W, (const T *)H, (T *)R);
+        TNMF_LAUNCH_CHECK();
+        return TNMF_OK;
     }
     hipLaunchKernelGGL(k_reconstruct<T>, dim3((unsigned)blocks), dim3(kBlock), lds, s, g, t, (const T *)W,
                        (const T *)H, (T *)R);
@@ -1062,11 +1093,29 @@ size_t schedule_lds(const Geo &g, const Tile &tR, const Tile &tW, const Tile &tH
 
 }  // namespace
 
+// largest slice (samples) whose reconstruct takes the small-call form, 0 for none; its LDS need
+template <typename T>
+static int schedule_small_max(const Geo &g, const Tile &tR, size_t *lds_small) {
+    Geo one = g;
+    one.N = 1;
+    if (!reconstruct_is_small<T>(one, tR, lds_small)) return 0;
+    const int per = g.C * tR.tiles_y * tR.tiles_x;   // blocks of the plain form per sample: small while N * per < 64
+    return per > 0 ? (63 / per) : 0;
+}
+
+static size_t schedule_lds_any(const Geo &g, int dtype, const Tile &tR, const Tile &tW, const Tile &tH, int *small_max) {
+    size_t lds = dtype == 0 ? schedule_lds<float>(g, tR, tW, tH) : schedule_lds<double>(g, tR, tW, tH);
+    size_t ls = 0;
+    *small_max = dtype == 0 ? schedule_small_max<float>(g, tR, &ls) : schedule_small_max<double>(g, tR, &ls);
+    if (*small_max > 0 && ls > lds) lds = ls;
+    return lds;
+}
+
 bool generic_schedule_fits(const tnmf_hip_ctx *, const Geo &g, int dtype) {
     const Tile tR = make_tile(g.Dy, g.Dx), tW = make_tile(g.Hy, g.Hx), tH = make_tile(g.Dy, g.Dx);
     if (g.Ay * g.Ax > kBlock * kMaxShiftsPerThread) return false;
-    const size_t lds = dtype == 0 ? schedule_lds<float>(g, tR, tW, tH) : schedule_lds<double>(g, tR, tW, tH);
-    return lds <= 64 * 1024;
+    int small_max = 0;
+    return schedule_lds_any(g, dtype, tR, tW, tH, &small_max) <= 64 * 1024;
 }
 
 // Workgroups of k_schedule that are resident AT ONCE on this device, capped at min(CUs, 128): the kernel's grid.  Its
@@ -1075,9 +1124,8 @@ bool generic_schedule_fits(const tnmf_hip_ctx *, const Geo &g, int dtype) {
 // kernel's real register / LDS footprint), not an assumption about "one workgroup of <= 64 KB per CU".  0: not even one.
 static int schedule_grid(const tnmf_hip_ctx *ctx, int dtype, size_t lds) {
     int per_cu = 0;
-    const hipError_t e = dtype == 0
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_schedule<float>, kBlock, lds)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_schedule<double>, kBlock, lds);
+    const hipError_t e = dtype == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_schedule<float>, kBlock, lds)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_schedule<double>, kBlock, lds);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return 0;
@@ -1114,19 +1162,18 @@ int generic_run_schedule(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void 
     a.reg = reg;
     a.eps = eps;
     a.counter = counter;
-    const size_t lds = dtype == 0 ? schedule_lds<float>(g, a.tR, a.tW, a.tH) : schedule_lds<double>(g, a.tR, a.tW, a.tH);
+    const size_t lds = schedule_lds_any(g, dtype, a.tR, a.tW, a.tH, &a.small_max);
     if (lds > 64 * 1024 || ctx->persistent == 0) return TNMF_E_UNSUPPORTED;
     // the whole grid must be resident at once (the barrier): as many workgroups as the occupancy query says fit, at most
-    // one per CU and 128 (the kernel's loops stride by gridDim.x: any grid size computes the same thing)
+    // one per CU and 128 (the kernel's loops stride by their number: any grid size computes the same thing)
     const int grid = schedule_grid(ctx, dtype, lds);
     if (grid < 1) return TNMF_E_UNSUPPORTED;   // (nothing launched, nothing written: the caller walks the list per operation)
     TNMF_HIP_TRY(hipMemsetAsync(counter, 0, 64 * sizeof(unsigned), s));
+    const void *fn = dtype == 0 ? (const void *)k_schedule<float> : (const void *)k_schedule<double>;
+    void *params[] = {&a};
     if (ctx->persistent == 2) {
         // cooperative launch: the runtime refuses a grid it cannot make co-resident instead of starting it
-        void *params[] = {&a};
-        const hipError_t e = hipLaunchCooperativeKernel(
-            dtype == 0 ? (const void *)k_schedule<float> : (const void *)k_schedule<double>, dim3(grid), dim3(kBlock), params,
-            (unsigned)lds, s);
+        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(kBlock), params, (unsigned)lds, s);
         if (e == hipErrorCooperativeLaunchTooLarge || e == hipErrorNotSupported) {
             (void)hipGetLastError();
             return TNMF_E_UNSUPPORTED;
@@ -1134,11 +1181,7 @@ int generic_run_schedule(tnmf_hip_ctx *ctx, const Geo &g, int dtype, const void 
         if (e != hipSuccess) return (int)e;
         return TNMF_OK;
     }
-    if (dtype == 0)
-        hipLaunchKernelGGL(k_schedule<float>, dim3(grid), dim3(kBlock), lds, s, a);
-    else
-        hipLaunchKernelGGL(k_schedule<double>, dim3(grid), dim3(kBlock), lds, s, a);
-    TNMF_LAUNCH_CHECK();
+    TNMF_HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(kBlock), params, lds, s));
     return TNMF_OK;
 }
 

@@ -74,7 +74,23 @@ struct SplitCfg {
     static constexpr int NP = (AY + 1) / 2;            // atom row pairs
     static constexpr int NSLOT = ONE_D ? NR4 / 2 : NP * NR4;   // (row pair, run) slots -- 1-D: pairs of runs; a k block holds two
     static constexpr int KB = (NSLOT + 1) / 2;
-    static constexpr int wimg = KB * 3 * 1024;         // bytes of the W image of one (atom tile, channel)
+    // The 16x16x32 form (see "The 16x16x32 form" in front of the kernel): 16 x 16 atoms always (M16AFF: four runs per atom
+    // row = the four 16-lane groups of a wave, all offsets affine); 12 x 12 atoms (three runs per row: the (row, run) slots in
+    // row-major order, K = 144 padded to 160) only with SEVERAL channels -- measured in same-box A/Bs, config-4 shard
+    // 4.69 -> 4.48 ms and 4.91 -> 4.79 ms on two devices, config 3 (one channel: the kernel is co-limited by its memory
+    // side and pays the padded half k block in full) 1.675 -> 1.710 ms and a tie (profiles/r04_ab_split12_16x16x32_*.txt).
+#ifdef TNMF_SPLIT_NO_M16
+    static constexpr bool m16(bool) { return false; }
+#elif defined(TNMF_SPLIT_NO_M16_12)
+    static constexpr bool m16(bool) { return AY == 16 && NR4 == 4; }
+#else
+    static constexpr bool m16(bool multi) { return (AY == 16 && NR4 == 4) || (AY == 12 && NR4 == 3 && multi); }
+#endif
+    static constexpr bool M16AFF = NR4 == 4;
+    static constexpr int NSLOT16 = AY * NR4;           // (atom row, run) slots of the 16x16x32 form, row-major
+    static constexpr int NKB16 = (NSLOT16 + 7) / 8;    // k blocks of 32 = eight slots
+    static constexpr int wimg16 = NKB16 * 6 * 1024, wimg32 = KB * 3 * 1024;   // bytes of the W image of one (atom tile, channel)
+    static constexpr int wimg = (m16(true) || m16(false)) && wimg16 > wimg32 ? wimg16 : wimg32;   // (room for either form)
     // Waves per workgroup: four (a tile of 8 rows, two workgroups per CU); EIGHT (16 rows, one W image for twice the pixels)
     // where a four-wave workgroup needs more than 80 KB of LDS and would sit alone on its CU with ONE wave per SIMD (16 x 16
     // atoms, the config-5 shard).  A lone wave leaves the matrix pipe idle in every bubble of its own instruction stream --
@@ -93,12 +109,6 @@ struct SplitCfg {
     static constexpr int win = 24 * planeB;            // 6 arrays x 4 copies
     static constexpr int lds = wimg + win;
     static constexpr int witems = SH * Q;              // staging items (window row, piece) per stage: one per thread
-    // M16: the 16 x 16 instantiation runs on v_mfma_f32_16x16x32_bf16 (see "The 16x16x32 form" in front of the kernel)
-#ifdef TNMF_SPLIT_NO_M16
-    static constexpr bool M16 = false;
-#else
-    static constexpr bool M16 = AY == 16 && NR4 == 4;
-#endif
     static_assert(witems <= kBlock, "one staging item per thread");
     static_assert(planeB % 8 == 0 && planeB % 256 == 64, "copy bases 64 bytes apart modulo the bank row");
 };
@@ -166,7 +176,7 @@ __device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// The 16x16x32 form (SplitCfg::M16: 16 x 16 atoms -- K = 256 per channel, no padding of K).  Under an MFMA-dense loop the
+// The 16x16x32 form (SplitCfg::m16(): 16 x 16 atoms -- K = 256 per channel, no padding of K).  Under an MFMA-dense loop the
 // chip holds a higher clock on v_mfma_f32_16x16x32_bf16 than on 32x32x16 at equal cycles per flop (MI355X_MICROARCH.md,
 // DVFS item 7: 1.12-1.15x the FLOP/s), and this instantiation is at its matrix ceiling.
 //   K order: k block kb = atom row pair (2 kb, 2 kb + 1); the four 16-lane groups kg of a wave take the four RUNS of an
@@ -182,17 +192,23 @@ __device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 //   adjacent lanes 128 contiguous bytes -- the same store shape as the 32x32 form, with one exchange instead of two.
 //   W image: [mt][c][kb (8)][ah (2)][term (3)][lane][8 bf16]: lane (i = l & 15, kg) of (kb, ah) holds taps
 //   (a = 2 kb + (j >> 2), b = 4 kg + (j & 3)) of atom 32 mt + 16 ah + i -- the same 48 KB per (atom tile, channel).
-__global__ void k_split_prep_W16(Geo g, const float *__restrict__ W, u32x4 *__restrict__ Wimg) {
+//   Three runs per atom row (12 x 12 atoms, K = 144 = 4.5 k blocks of 32: the last half block is zeros in the image): the
+//   36 (row, run) slots in row-major order, slot 8 kb + kg + 4 e for lane group kg and lane half-vector e.  The two groups
+//   of a 32-lane half then read CONSECUTIVE slots -- the next run of the same row (8 bytes on: the pieces overlap,
+//   broadcast) or run 0 of the next row (80 - 16 = 64 bytes on: the other half of the 128-byte bank window) -- conflict-free
+//   again; their window offsets are not affine in the lane: three per-lane base registers (see `ap` in the kernel).
+__global__ void k_split_prep_W16(Geo g, int NKB, int NR4, int NSLOT, const float *__restrict__ W, u32x4 *__restrict__ Wimg) {
     const int lane = threadIdx.x;
-    const int ah = blockIdx.x & 1, kb = (blockIdx.x >> 1) & 7;
-    const int c = (blockIdx.x >> 4) % g.C;
-    const int mt = blockIdx.x / (16 * g.C);
+    const int ah = blockIdx.x & 1, kb = (blockIdx.x >> 1) % NKB;
+    const int c = (blockIdx.x / (2 * NKB)) % g.C;
+    const int mt = blockIdx.x / (2 * NKB * g.C);
     const int m = mt * 32 + 16 * ah + (lane & 15), kg = lane >> 4;
     unsigned t[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int a = 2 * kb + (j >> 2), b = 4 * kg + (j & 3);
-        const bool ok = a < g.Ay && b < g.Ax && m < g.M;
+        const int slot = 8 * kb + kg + 4 * (j >> 2);
+        const int a = slot / NR4, b = 4 * (slot - a * NR4) + (j & 3);   // (four runs per row: a = 2 kb + (j >> 2), run kg)
+        const bool ok = slot < NSLOT && a < g.Ay && b < g.Ax && m < g.M;
         const float w = ok ? W[(((size_t)m * g.C + c) * g.Ay + a) * g.Ax + b] : 0.f;
         split3(w, t[0][j], t[1][j], t[2][j]);
     }
@@ -201,7 +217,7 @@ __global__ void k_split_prep_W16(Geo g, const float *__restrict__ W, u32x4 *__re
         u32x4 v;
 #pragma unroll
         for (int d = 0; d < 4; ++d) v[d] = t[term][2 * d] | (t[term][2 * d + 1] << 16);
-        Wimg[((((size_t)(mt * g.C + c) * 8 + kb) * 2 + ah) * 3 + term) * 64 + lane] = v;
+        Wimg[((((size_t)(mt * g.C + c) * NKB + kb) * 2 + ah) * 3 + term) * 64 + lane] = v;
     }
 }
 
@@ -248,7 +264,9 @@ __global__ __launch_bounds__((SplitCfg<AY, NR4>::kBlock), 2) TNMF_NO_DS_PAIRING 
     static_assert(!EXTRA || FUSED, "the extra denominator term belongs to the fused update");
     using Cfg = SplitCfg<AY, NR4>;
     constexpr int WSTR = Cfg::WSTR, Q = Cfg::Q, planeB = Cfg::planeB, KB = Cfg::KB, NSLOT = Cfg::NSLOT, NP = Cfg::NP;
-    constexpr bool ONE_D = Cfg::ONE_D, M16 = Cfg::M16;
+    // (the extra-term epilogue keeps 32 more registers alive: with several channels it stays on the 32x32x16 form, where it
+    // fits without spills)
+    constexpr bool ONE_D = Cfg::ONE_D, M16 = Cfg::m16(MULTI) && !(EXTRA && MULTI);
     constexpr int kBlock = Cfg::kBlock, SP_TY = Cfg::TY;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Wl = smem;                  // [KB][3][64 lanes][16 bytes]
@@ -280,21 +298,22 @@ __global__ __launch_bounds__((SplitCfg<AY, NR4>::kBlock), 2) TNMF_NO_DS_PAIRING 
     // chunks of up to 8 pieces whose loads are all issued before the first store (one memory round trip per chunk, not
     // one per piece).  MULTI (several channels, compile time): the image changes every stage; the first chunk is loaded
     // BEFORE the barrier that frees the previous image and stored behind it.
-    constexpr int NPW = (KB * 3 * 64 + kBlock - 1) / kBlock, WCH = 8, NWCH = (NPW + WCH - 1) / WCH;
+    constexpr int WPIECES = (M16 ? Cfg::wimg16 : Cfg::wimg32) / 16;   // 16-byte pieces of one W image
+    constexpr int NPW = (WPIECES + kBlock - 1) / kBlock, WCH = 8, NWCH = (NPW + WCH - 1) / WCH;
     u32x4 wtmp[WCH];
     auto load_W = [&](int c, int chunk) {
-        const u32x4 *src = Wimg + (size_t)(mt * g.C + c) * (KB * 3 * 64);
+        const u32x4 *src = Wimg + (size_t)(mt * g.C + c) * WPIECES;
 #pragma unroll
         for (int k = 0; k < WCH; ++k) {
             const int i = threadIdx.x + (chunk * WCH + k) * kBlock;
-            if (chunk * WCH + k < NPW) wtmp[k] = src[i < KB * 3 * 64 ? i : 0];
+            if (chunk * WCH + k < NPW) wtmp[k] = src[i < WPIECES ? i : 0];
         }
     };
     auto store_W = [&](int chunk) {
 #pragma unroll
         for (int k = 0; k < WCH; ++k) {
             const int i = threadIdx.x + (chunk * WCH + k) * kBlock;
-            if (chunk * WCH + k < NPW && i < KB * 3 * 64) reinterpret_cast<u32x4 *>(Wl)[i] = wtmp[k];
+            if (chunk * WCH + k < NPW && i < WPIECES) reinterpret_cast<u32x4 *>(Wl)[i] = wtmp[k];
         }
     };
     if (!MULTI) {
@@ -488,10 +507,24 @@ __global__ __launch_bounds__((SplitCfg<AY, NR4>::kBlock), 2) TNMF_NO_DS_PAIRING 
     // (M16: tile column jc = lane & 15 is pixel 4 (jc & 7) + 2 (jc >> 3) + ph: window copy 2 (jc >> 3) + ph, the ph in the
     // compile-time offset; lane group kg = lane >> 4 is 4 kg taps further along the row)
     const unsigned char *abase =
-        M16 ? Xw + 2 * ((lane >> 3) & 1) * planeB + ((2 * wave) * WSTR + 4 * (lane & 7) + 4 * (lane >> 4)) * 2
+        M16 ? Xw + 2 * ((lane >> 3) & 1) * planeB +
+                  ((2 * wave) * WSTR + 4 * (lane & 7) + (Cfg::M16AFF ? 4 * (lane >> 4) : 0)) * 2
             : Xw + (j >> 3) * planeB +
                   (ONE_D ? (2 * wave) * WSTR + 4 * (j & 7) + 8 * h : (2 * wave + h) * WSTR + 4 * (j & 7)) * 2;
     const unsigned char *bbase = Wl + lane * 16;
+    // 16x16x32 form, three runs per row: with c = 8 kb + 4 e = 3 c3 + cr the slot of lane group kg is (atom row
+    // c3 + (cr + kg) / 3, run (cr + kg) % 3): the row c3 goes into the immediate offset of the read and only THREE
+    // lane-dependent bases remain, one per cr.
+    const unsigned char *ap[3];
+    if constexpr (M16 && !Cfg::M16AFF) {
+#pragma unroll
+        for (int cr = 0; cr < 3; ++cr) {
+            const int t = cr + (lane >> 4);
+            ap[cr] = abase + ((t / 3) * WSTR + 4 * (t % 3)) * 2;
+        }
+    } else {
+        ap[0] = ap[1] = ap[2] = abase;
+    }
 
     f32x16 acc[SP_RB][2];   // [row of the wave][V | R]
     // M16: the same 64 registers as sixteen 16 x 16 tiles [row of the wave][V | R][atom half][pixel half]; acc[][] is
@@ -609,17 +642,22 @@ __global__ __launch_bounds__((SplitCfg<AY, NR4>::kBlock), 2) TNMF_NO_DS_PAIRING 
             // W operand (two atom halves x three terms, 24 registers) serves the eight groups of a k block and is single
             // buffered: the next k block's first half is re-read in the shadow of the last group's second six MFMAs, its
             // second half under the first six MFMAs of the next group (a second register set does not fit: 238 of 256).
-            constexpr int NKB = 8, G = NKB * 8;
+            constexpr int NKB = Cfg::NKB16, G = NKB * 8;
             u32x2 a[2][3][2];   // [buffer][term][atom row of the pair]
             u32x4 b[2][3];      // [atom half][term]
             auto load_a = [&](int buf, int gi) {
                 const int kb = gi >> 3, rb = (gi >> 2) & 1, x = (gi >> 1) & 1, ph = gi & 1;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int off = ph * planeB + ((rb + 2 * kb + e) * WSTR) * 2;
+                    // four runs per row: everything but the lane base is an immediate; three: the slot's base + immediate
+                    // (slots beyond the atom -- the second half of the last k block of 12 x 12 atoms -- read the last real
+                    // rows: W is zero there)
+                    const int cslot = 8 * kb + 4 * e, c3 = cslot / 3 < AY - 2 ? cslot / 3 : AY - 2;
+                    const unsigned char *base = Cfg::M16AFF ? abase : ap[cslot % 3];
+                    const int off = ph * planeB + ((rb + (Cfg::M16AFF ? 2 * kb + e : c3)) * WSTR) * 2;
 #pragma unroll
                     for (int term = 0; term < 3; ++term)
-                        a[buf][term][e] = *reinterpret_cast<const u32x2 *>(abase + (3 * x + term) * 4 * planeB + off);
+                        a[buf][term][e] = *reinterpret_cast<const u32x2 *>(base + (3 * x + term) * 4 * planeB + off);
                 }
             };
             auto load_b = [&](int ah, int kb) {
@@ -636,7 +674,7 @@ __global__ __launch_bounds__((SplitCfg<AY, NR4>::kBlock), 2) TNMF_NO_DS_PAIRING 
                 constexpr int kb = gi >> 3, rb = (gi >> 2) & 1, x = (gi >> 1) & 1, ph = gi & 1;
                 constexpr int ab = gi & 1;
                 constexpr bool nextb = (gi & 7) == 7 && kb + 1 < NKB;
-                constexpr int MSTRIDE = G / 24;
+                constexpr int MSTRIDE = G >= 24 ? G / 24 : 1;
                 if constexpr (gi + 1 < G) load_a(ab ^ 1, gi + 1);
                 if constexpr (gi % MSTRIDE == 0 && gi / MSTRIDE < 12) mem_slot(gi / MSTRIDE);
                 __builtin_amdgcn_sched_barrier(0);
@@ -923,8 +961,9 @@ int launch(tnmf_hip_ctx *ctx, const Geo &g, const float *V, const float *R, cons
         }
         ctx->wimg_bytes = wbytes;
     }
-    if constexpr (Cfg::M16)
-        hipLaunchKernelGGL(k_split_prep_W16, dim3(MT * g.C * 16), dim3(64), 0, s, g, W, (u32x4 *)ctx->wimg);
+    if (Cfg::m16(g.C > 1) && !(fused && extra && g.C > 1))   // (the form the kernel instantiation below runs on)
+        hipLaunchKernelGGL(k_split_prep_W16, dim3(MT * g.C * Cfg::NKB16 * 2), dim3(64), 0, s, g, Cfg::NKB16, NR4,
+                           Cfg::NSLOT16, W, (u32x4 *)ctx->wimg);
     else
         hipLaunchKernelGGL(k_split_prep_W, dim3(MT * g.C * Cfg::KB), dim3(64), 0, s, g, Cfg::NP, Cfg::NSLOT, Cfg::KB,
                            Cfg::ONE_D ? 1 : 0, W, (u32x4 *)ctx->wimg);
