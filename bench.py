@@ -390,13 +390,14 @@ def main():
             return launch_scale * tiles * 4 * kb * 4 * 6 * (2.0 * 32 * 32 * 16)
         ay, ax = cfg['A']
         # the instantiation that runs the shape (split.hip: the covering (atom rows, runs of four taps) pair with the
-        # fewest k blocks); 12 x 12 and 16 x 16 run on v_mfma_f32_16x16x32_bf16 (k blocks of 32 = eight (row, run) slots)
+        # fewest k blocks); 16 x 16 atoms, and 12 x 12 atoms with several channels, run on v_mfma_f32_16x16x32_bf16 (k blocks
+        # of 32 = eight (row, run) slots)
         cover = [(a, r) for a, r in ((12, 3), (9, 3), (16, 4), (7, 2), (8, 2), (5, 2)) if a >= ay and 4 * r >= ax]
         if not cover:
             return None
         ai, ri = min(cover, key=lambda ar: (((ar[0] + 1) // 2) * ar[1] + 1) // 2)
         tiles = n_local * -(-Hs[0] // 8) * -(-Hs[1] // 32) * -(-cfg['M'] // 32) * cfg['C']
-        if (ai, ri) in ((12, 3), (16, 4)):
+        if (ai, ri) == (16, 4) or ((ai, ri) == (12, 3) and cfg['C'] > 1):   # (12 x 12: with several channels only)
             kb32 = -(-ai * ri // 8)
             # per wave (two rows of the tile) and k block: 8 groups (row, V | R, pixel half) x 2 atom halves x 6 products
             return launch_scale * tiles * 4 * kb32 * 8 * 12 * (2.0 * 16 * 16 * 32)

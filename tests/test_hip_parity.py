@@ -308,6 +308,11 @@ SPLIT_SHAPES = [
     (1, 1, (30, 30), 4, (11, 5)),
     (1, 1, (25, 40), 6, (3, 16)),
     (2, 1, (20, 20), 5, (3, 3)),
+    # the 16x16x32 forms (round 4): 12-row instantiation with several channels on atoms it pads (odd height, taps not a
+    # multiple of four), 16-row instantiation with one channel and a partial atom tile
+    (2, 3, (30, 40), 12, (11, 9)),
+    (1, 2, (26, 70), 35, (12, 12)),
+    (2, 1, (40, 36), 20, (15, 13)),
 ]
 
 

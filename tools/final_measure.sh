@@ -2,7 +2,8 @@
 # Round-end measurement batch on the GPU box: bench lines, rocprof kernel stats and FETCH/WRITE PMC passes of every
 # BASELINE configuration that fits one GPU (2, 3, 4-shard, 5-shard), Cyclic-MU lines of configs 4 and 5, the small-batch
 # schedules, the inhibition leg.
-# usage (through gpurun): bash tools/final_measure.sh <tag> [configs, default "3 2 4 5"] [nobench]  -> gpurun_out/final_<tag>/
+# usage (through gpurun): bash tools/final_measure.sh <tag> [configs, default "3 2 4 5"] [nobench|noprof]  -> gpurun_out/final_<tag>/
+# (the whole batch is longer than one gpurun call allows: run it as `... <tag> "3 2 4 5" noprof` and `... <tag> "3 2 4 5" nobench`)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=${1:-r}
 configs=${2:-"3 2 4 5"}
@@ -32,6 +33,7 @@ if [ "$3" != "nobench" ]; then
   done
   echo "bench legs done"
 fi
+if [ "$3" == "noprof" ]; then echo "all done (no profiles)"; exit 0; fi
 cd /tmp && export TMPDIR=/tmp
 PROF_ARGS="--steps 10 --warmup 2 $Q"
 for c in $configs; do
