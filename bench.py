@@ -10,11 +10,22 @@ bench.py -- MU-iterations/sec of the shift-invariant multiplicative-update loop 
 One step = one full MU iteration (H half step + W half step, TransformInvariantNMF.py:334-340 of the reference) over
 the rank's resident samples, driven through the product front-end and the C ABI, with V, W, H already in HBM.
 Workload: BASELINE.json configs[2] = 256 samples x 1 channel x 256x256, 32 atoms 12x12, float32, synthetic planted
-model.  With N > 1 ranks every rank holds one such shard (weak scaling: 256 samples per GPU, global N = 256 * ranks);
-the only exchange is one all-reduce (RCCL) of the 2 x 32 x 1 x 12 x 12 W numerator/denominator per iteration.
+model.  With N > 1 ranks every rank holds one such shard -- and only that: HIP_Backend(sharded_input=True) -- (weak scaling:
+256 samples per GPU, global N = 256 * ranks); the only exchange is one all-reduce (RCCL) of the 2 x 32 x 1 x 12 x 12 W
+numerator/denominator per iteration.
 
 `value` = (shard-iterations completed by all ranks) / (max-over-ranks wall time), i.e. at --gpus 1 exactly the
 MU-iterations/sec of the 256-sample problem and at --gpus N the iterations/sec of N such problems run as one job.
+
+`python bench.py --gpus N` WITHOUT WORLD_SIZE in the environment starts the N ranks itself (a child process running
+torch.distributed.run; this process never touches the GPU) and relays rank 0's line.  At N > 1 the line also carries
+  strong_scaling   config 3 as ONE problem (256 global samples, 256 / N per GPU), iterations/sec of the global problem, with the
+                   same problem on one GPU in the same run (rank 0 alone) and the measured speed-up / efficiency beside it
+  config4_cyclic, config5_cyclic   BASELINE configs[3] / configs[4] as worded: Cyclic-MU epochs, sample-sharded (the per-GPU
+                   shards 256 x 3 x 256^2 / 128 x 3 x 512^2 on every rank), ONE collective per epoch
+  rccl_ranks_seen, distributed   an all-reduce of one 1.0 per rank (the ranks the collective reached), backend, latency of the
+                   gradient exchange, rank / device / pid of every rank
+(--legs selects them; TNMF_BENCH_DIST_BACKEND=gloo lets several ranks share the GPUs of a smaller box: a rehearsal.)
 
 --algorithm cyclic: one step = one Cyclic-MU epoch (reference TransformInvariantNMF.py:457-465) over the rank's samples in
 mini-batches of --batch-size (global batch = the union of the ranks' local batches; one all-reduce per epoch) -- the
