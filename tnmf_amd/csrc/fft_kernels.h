@@ -767,8 +767,11 @@ int fft_run_typed(int op, const FftArgs *a, hipStream_t s) {
                             (size_t)L * (NBM + 1) * sizeof(cplx<T>) + tw_bytes + stash);
         }
         case kFftColsFwd:
-            // (a persistent form -- a workgroup walks tiles with the next tile prefetched into registers -- was measured in
-            // round 4 and not kept: no gain over three one-tile workgroups per CU, profiles/r04_ab_cols_persistent_vs_plain.txt)
+            // (measured in round 4 and not kept: a persistent form -- a workgroup walks tiles with the next tile prefetched
+            // into registers: no gain over three one-tile workgroups per CU, profiles/r04_ab_cols_persistent_vs_plain.txt --
+            // and a whole-line form -- 16-column tiles transformed as two halves of eight: slower, 7.9 vs 7.55 ms for the
+            // reconstruct group at the config-5 shard; with the three LDS stages removed altogether the group still takes
+            // 7.0-7.2 ms, profiles/r04_ab_cols_whole_lines_and_stage_ablation.txt)
             TNMF_FFT_LAUNCH((k_fft_cols_fwd<T, L, NTC>), dim3(tiles, (unsigned)a->planes), NTC, col_lds);
         case kFftColsInv:
             TNMF_FFT_LAUNCH((k_fft_cols_inv<T, L, NTC>), dim3(tiles, (unsigned)a->planes), NTC, col_lds);
