@@ -619,7 +619,7 @@ def main():
     main_family = ('hybrid' if 'fft' in fams and (fams & {'mfma', 'split', 'generic'}) else last_family)
     if 'split' in fams:
         main_family += '+split' if main_family != 'split' else ''
-    if world == 1 and not args.no_fft_variant and k == 2:
+    if world == 1 and group is None and not args.no_fft_variant and k == 2:   # (with a process group the main model is gone)
         W_main = nmf.W
         legs = [('mfma', 'direct_variant', True), ('fft', 'fft_variant', True)]
         if 'split' in fams:
