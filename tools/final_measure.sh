@@ -41,13 +41,15 @@ for c in $configs; do
   echo "stats config $c done"
   for cnt in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $cnt --output-format csv -d $out/pmc_config$c/$cnt -- python3 $R/bench.py --config $c $PROF_ARGS > $out/pmc_config${c}_$cnt.log 2>&1 || { echo "pmc $c $cnt failed"; exit 1; }
+    # the same with 4 timed steps: the per-iteration traffic is the difference of the two runs (set-up launches cancel)
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $cnt --output-format csv -d $out/pmc_short_config$c/$cnt -- python3 $R/bench.py --config $c --steps 4 --warmup 2 $Q > $out/pmc_short_config${c}_$cnt.log 2>&1 || { echo "pmc short $c $cnt failed"; exit 1; }
   done
   echo "pmc config $c done"
 done
 cd $R
 for c in $configs; do
-  python3 tools/traffic_from_pmc.py $out/pmc_config$c $c 12 $out/traffic_config$c.json || exit 1
+  python3 tools/traffic_from_pmc.py $out/pmc_config$c $c 10 $out/traffic_config$c.json $out/pmc_short_config$c 4 || exit 1
   cp $(find $out/stats_config$c -name '*kernel_stats.csv' | head -1) $out/rocprof_kernel_stats_config$c.csv || exit 1
-  rm -rf $out/pmc_config$c $out/stats_config$c     # (raw traces: tens of MB)
+  rm -rf $out/pmc_config$c $out/pmc_short_config$c $out/stats_config$c     # (raw traces: tens of MB)
 done
 echo all done
