@@ -555,7 +555,23 @@ def main():
         def leg_kernels(sp, pth):
             return {nm: {'launches': len(ms), 'avg_ms': float(np.mean(ms)), 'family': pth.get(nm)} for nm, ms in sp.items()}
 
-        if 'strong' in want:
+        def guarded(name, fn):
+            """One further leg; a failure on any rank (a shape the device cannot hold, ...) becomes an `error` entry on the
+            line instead of taking the headline down with it.  (A rank that dies INSIDE a collective cannot be caught.)"""
+            err, res = None, None
+            try:
+                res = fn()
+            except Exception as exc:   # noqa: BLE001
+                err = repr(exc)[:300]
+            bad = torch.tensor([1.0 if err else 0.0], dtype=torch.float32, device=device)
+            dist.all_reduce(bad)
+            if float(bad.item()) > 0:
+                torch.cuda.empty_cache()
+                scaling_legs[name] = {'error': err or 'failed on another rank', 'ranks_failed': int(round(float(bad.item())))}
+            else:
+                scaling_legs[name] = res
+
+        def leg_strong():
             # STRONG scaling of the headline problem: cfg['N'] (256) GLOBAL samples, ceil(256 / N) per GPU (this rank takes
             # them from the front of its own synthetic block), one W collective per iteration; beside it the same problem
             # on ONE GPU without a process group (rank 0, its whole block), in the same run.
@@ -571,7 +587,7 @@ def main():
                 del m_1
                 torch.cuda.empty_cache()
             dist.barrier()
-            scaling_legs['strong_scaling'] = {
+            return {
                 'what': f'config 3 as ONE problem: {n_glob_s} global samples, {hi - lo} on rank 0, full-batch MU, one '
                         f'collective of the W numerator / denominator per iteration',
                 'value': ls / el_s, 'unit': 'MU-iterations/sec (of the global problem)', 'scaling': 'strong',
@@ -582,9 +598,8 @@ def main():
                 'efficiency': (el_1 / el_s / world) if el_1 else None,
                 'kernels': leg_kernels(sp_s, pth_s), 'energy_after_run': e_s,
             }
-        for leg, cid, local_batch in (('config4', 4, 64), ('config5', 5, 32)):
-            if leg not in want:
-                continue
+
+        def leg_cyclic(cid, local_batch):
             # BASELINE configs[3] / configs[4]: mini-batch (Cyclic) MU, sample-sharded, ONE W collective per epoch; every
             # GPU holds the per-GPU shard of the 8-GPU problem (at N = 8 this IS the configuration; at N < 8 the same
             # shards, i.e. a problem of N / 8 of its size)
@@ -600,7 +615,7 @@ def main():
             n_glob_c = m_c._backend.n_samples
             del m_c, Vc
             torch.cuda.empty_cache()
-            scaling_legs[leg + '_cyclic'] = {
+            return {
                 'what': f'BASELINE.json configs[{cid - 1}] as worded: Cyclic-MU epochs (reference TransformInvariantNMF.py:'
                         f'457-465), sample-sharded, {c["N"]} samples x {c["C"]} ch x {"x".join(map(str, c["D"]))} per GPU, '
                         f'{c["M"]} atoms {"x".join(map(str, c["A"]))}, global batch {local_batch * world} = {local_batch} '
@@ -611,6 +626,12 @@ def main():
                 'sample_epochs_per_sec': n_glob_c * steps_c / el_c,
                 'kernels': leg_kernels(sp_c, pth_c), 'energy_after_run': e_c,
             }
+
+        if 'strong' in want:
+            guarded('strong_scaling', leg_strong)
+        for leg, cid, local_batch in (('config4', 4, 64), ('config5', 5, 32)):
+            if leg in want:
+                guarded(leg + '_cyclic', lambda cid=cid, local_batch=local_batch: leg_cyclic(cid, local_batch))
 
     # Further legs (single GPU only): the same iterations from the same start on the other kernel families -- the
     # direct-vs-FFT crossover of BASELINE.json configs[4].
