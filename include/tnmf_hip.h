@@ -241,7 +241,11 @@ int tnmf_hip_grad_W_fused(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
  *   TNMF_OP_APPLY_W   W = W * acc_neg / (acc_pos + eps), normalised; acc_pos is left incremented by eps (:232)
  * geom->N = samples of the resident problem (V, H_inout point at sample 0); acc: device buffer [2,M,C,*A] that persists
  * between calls where the schedule says so (ASAG / GSAG).  Single device: with several ranks the gradient must be summed
- * across them between GRAD_W and APPLY_W, which is the caller's collective. */
+ * across them between GRAD_W and APPLY_W, which is the caller's collective.
+ * A RUN of consecutive TNMF_OP_UPDATE_H operations on pairwise disjoint sample ranges is executed as the H half step of
+ * their union (ranges sorted and joined where they touch): such steps commute -- the H update of a sample reads that sample
+ * and W only, and W does not change inside the run -- so GSG-MU / GSAG-MU (:474-479, :493-504: H for every shuffled batch, W
+ * from the last batch) cost one H half step over all samples per epoch, not one launch chain per batch. */
 enum { TNMF_OP_UPDATE_H = 0, TNMF_OP_GRAD_W = 1, TNMF_OP_APPLY_W = 2 };
 typedef struct {
     int kind;    /* TNMF_OP_* */

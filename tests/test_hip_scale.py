@@ -802,6 +802,46 @@ def test_schedules_in_one_call_match_the_batch_by_batch_path(algorithm, dtype, t
     assert relmax(got['one_call'][0], got['batch_by_batch'][0]) < (1e-13 if dtype == np.float64 else 1e-6)
 
 
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-11), (np.float32, 2e-6)], ids=['f64', 'f32'])
+def test_runs_of_h_steps_are_joined_only_when_they_commute(dtype, tol):
+    """tnmf_hip_run_schedule executes a run of consecutive H half steps on pairwise DISJOINT sample ranges as the H half
+    step of their union (GSG / GSAG: one launch chain per epoch instead of one per batch) -- the same result as one call
+    per step, in any order of the steps; a run with OVERLAPPING ranges is left alone (an H step is not idempotent: the
+    second step on a sample must see the first)."""
+    N, C, D, M, A = 40, 1, (32, 32), 10, (7, 7)     # (large enough not to be a 'tiny' problem: the per-operation path)
+    V = planted_V(N, C, D, M, A, seed=31, dtype=dtype, density=0.05)
+
+    def fresh():
+        be = HIP_Backend()
+        np.random.seed(3)
+        W, H = be.initialize(V, A, M, None, (-2, -1))
+        return be, W, H
+
+    def steps(ops_lists):
+        be, W, H = fresh()
+        acc = be.new_gradient_accumulator(W)
+        for ops in ops_lists:
+            be.run_schedule(V, W, H, ops, acc, sparsity=0.05)
+        return be.to_ndarray(H), be.to_ndarray(W)
+
+    tail = [('G', slice(5, 9), 0., 1.), ('W',)]
+    # disjoint, shuffled, with a gap (samples 20..24 are not updated) and an empty slice
+    run = [('H', slice(30, 40)), ('H', slice(0, 5)), ('H', slice(9, 9)), ('H', slice(10, 20)), ('H', slice(5, 10)),
+           ('H', slice(25, 30))]
+    H1, W1 = steps([run + tail])
+    H2, W2 = steps([[op] for op in run] + [tail])
+    assert relmax(H1, H2) < tol and relmax(W1, W2) < tol
+    be0, _, H0 = fresh()
+    assert np.array_equal(H1[20:25], be0.to_ndarray(H0)[20:25])              # the gap was left alone
+    # overlapping: samples 10..14 are updated twice, in order
+    lap = [('H', slice(0, 15)), ('H', slice(10, 25))]
+    H3, _ = steps([lap])
+    H4, _ = steps([[lap[0]], [lap[1]]])
+    H5, _ = steps([[('H', slice(0, 25))]])
+    assert relmax(H3, H4) < tol
+    assert relmax(H3[10:15], H5[10:15]) > 1e-3                               # (... which is NOT what one joined step gives)
+
+
 def test_inhibition_kernels_beyond_the_fused_kernel_fall_back_to_the_reference_lines():
     """A 127-tap inhibition kernel (range 63) in float64 does not fit the LDS tile of the lateral-term kernel: the library
     answers TNMF_E_UNSUPPORTED before touching H, the backend turns that into NotImplementedError and the front end walks

@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
+#include <vector>
 
 #include "fft.h"
 #include "generic.h"
@@ -948,15 +950,51 @@ int tnmf_hip_run_schedule(tnmf_hip_ctx *ctx, const tnmf_hip_geom *geom, const vo
     const size_t wn = (size_t)g.M * g.C * g.Ay * g.Ax;
     // scratch for the largest slice of the list: R of the slice (unless the caller brought one), split-K partials, and the
     // gradient of one batch behind them
-    int nmax = 1;
     for (int i = 0; i < n_ops; ++i) {
         // (checked for the whole list before anything runs: the persistent kernel walks it on the device)
         if (ops[i].kind != TNMF_OP_UPDATE_H && ops[i].kind != TNMF_OP_GRAD_W && ops[i].kind != TNMF_OP_APPLY_W)
             return TNMF_E_UNSUPPORTED;
         if (ops[i].kind == TNMF_OP_APPLY_W) continue;
         if (ops[i].n0 < 0 || ops[i].n1 < ops[i].n0 || ops[i].n1 > g.N) return TNMF_E_GEOM;
-        if (ops[i].n1 - ops[i].n0 > nmax) nmax = ops[i].n1 - ops[i].n0;
     }
+    // Consecutive H half steps commute when their slices are disjoint -- the H update of a sample reads that sample and W
+    // only (NumPy.py:93-120), and W does not change between them -- so a RUN of them is executed as the H half step of the
+    // union: the slices sorted and joined where they touch.  GSG-MU / GSAG-MU (TransformInvariantNMF.py:474-479,493-504: H for
+    // every shuffled batch, W from the last one only) become ONE H half step over all samples + one W step per epoch instead
+    // of 256 x 2 launches of three samples each.  Runs with overlapping slices are left as they are (an H step is not
+    // idempotent).  Same arithmetic per sample; the kernel family follows the size of the joined slice.
+    std::vector<tnmf_hip_op> joined;
+    joined.reserve(n_ops);
+    for (int i = 0; i < n_ops;) {
+        if (ops[i].kind != TNMF_OP_UPDATE_H) {
+            joined.push_back(ops[i++]);
+            continue;
+        }
+        int j = i;
+        while (j < n_ops && ops[j].kind == TNMF_OP_UPDATE_H) ++j;
+        std::vector<tnmf_hip_op> run(ops + i, ops + j);
+        run.erase(std::remove_if(run.begin(), run.end(), [](const tnmf_hip_op &o) { return o.n1 <= o.n0; }), run.end());
+        std::vector<tnmf_hip_op> sorted_run = run;
+        std::sort(sorted_run.begin(), sorted_run.end(), [](const tnmf_hip_op &a, const tnmf_hip_op &b) { return a.n0 < b.n0; });
+        bool disjoint = true;
+        for (size_t k = 1; k < sorted_run.size(); ++k) disjoint = disjoint && sorted_run[k].n0 >= sorted_run[k - 1].n1;
+        if (!disjoint) {
+            joined.insert(joined.end(), run.begin(), run.end());
+        } else {
+            for (size_t k = 0; k < sorted_run.size(); ++k) {
+                if (!joined.empty() && joined.back().kind == TNMF_OP_UPDATE_H && k > 0 && joined.back().n1 == sorted_run[k].n0)
+                    joined.back().n1 = sorted_run[k].n1;
+                else
+                    joined.push_back(sorted_run[k]);
+            }
+        }
+        i = j;
+    }
+    ops = joined.data();
+    n_ops = (int)joined.size();
+    int nmax = 1;
+    for (int i = 0; i < n_ops; ++i)
+        if (ops[i].kind != TNMF_OP_APPLY_W && ops[i].n1 - ops[i].n0 > nmax) nmax = ops[i].n1 - ops[i].n0;
     double reg = eps;
     if (sparsity > 0) reg += sparsity;  // TransformInvariantNMF.py:227-230
     // A whole problem that is tiny (BASELINE config 1): every kernel would run for a few microseconds and the list would be
