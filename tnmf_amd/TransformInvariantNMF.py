@@ -45,6 +45,28 @@ def _permuted(items: list) -> list:
     return [items[i] for i in order]
 
 
+def _joined(batches: list) -> list:
+    """A run of H half steps on pairwise disjoint sample slices commutes (the H update of a sample reads that sample and W
+    only, reference :246-271, and W does not change inside the run): the slices sorted and joined where they touch.
+    Overlapping or strided slices: the list as it is."""
+    spans = []
+    for b in batches:
+        if b.step not in (None, 1) or b.start is None or b.stop is None or b.start < 0 or b.stop < 0:
+            return list(batches)
+        if b.stop > b.start:
+            spans.append((b.start, b.stop))
+    spans.sort()
+    if any(spans[i][0] < spans[i - 1][1] for i in range(1, len(spans))):
+        return list(batches)
+    out = []
+    for lo, hi in spans:
+        if out and out[-1][1] == lo:
+            out[-1][1] = hi
+        else:
+            out.append([lo, hi])
+    return [slice(lo, hi) for lo, hi in out]
+
+
 def _backend_registry():
     from .backends.HIP import HIP_Backend
     return {'hip': HIP_Backend}
@@ -363,8 +385,10 @@ class TransformInvariantNMF:
             run(self._V, self._W, self._H, ops, self._backend.new_gradient_accumulator(self._W),
                 sparsity=h_args['sparsity'], eps=self.eps)
             return None
-        for batch in _permuted(batches):
-            self._update_H(batch, **h_args)
+        order = _permuted(batches)
+        batch = order[-1] if len(order) else batch
+        for run_ in _joined(order):     # (the H steps of an epoch commute: one call per contiguous run of samples)
+            self._update_H(run_, **h_args)
         self._update_W(batch)
         return None
 
@@ -398,8 +422,10 @@ class TransformInvariantNMF:
             ops += [('G', order[-1] if len(order) else batch) + self._blend_coefficients(first, lam), ('W',)]
             run(self._V, self._W, self._H, ops, acc, sparsity=h_args['sparsity'], eps=self.eps)
             return acc
-        for batch in _permuted(batches):
-            self._update_H(batch, **h_args)
+        order = _permuted(batches)
+        batch = order[-1] if len(order) else batch
+        for run_ in _joined(order):
+            self._update_H(run_, **h_args)
         state = self._blend_gradient_W(state, lam, batch)
         self._apply_accumulated_W(state)
         return state
