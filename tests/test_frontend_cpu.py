@@ -113,3 +113,22 @@ def test_tiny_full_batch_iterations_go_out_as_operation_lists():
     ref.fit(V_1D, n_iterations=4, sparsity_H=0.1)
     np.testing.assert_allclose(nmf.W, ref.W, rtol=1e-12)
     np.testing.assert_allclose(nmf.H, ref.H, rtol=1e-12)
+
+
+def test_commuting_h_steps_are_joined_in_the_step_by_step_schedules():
+    """GSG / GSAG driven step by step (several ranks, or no schedule support): the H steps of an epoch are issued per
+    contiguous run of samples, not per batch -- and only when the batches are plain disjoint slices."""
+    from tnmf_amd.TransformInvariantNMF import _joined
+    assert _joined([slice(6, 9), slice(0, 3), slice(3, 6)]) == [slice(0, 9)]
+    assert _joined([slice(6, 9), slice(0, 3), slice(4, 4)]) == [slice(0, 3), slice(6, 9)]            # a gap, an empty batch
+    lap = [slice(0, 4), slice(3, 6)]
+    assert _joined(lap) == lap                                                                       # overlapping: as given
+    assert _joined([slice(None)]) == [slice(None)]                                                   # batch_size=None
+    strided = [slice(0, 6, 2), slice(6, 9)]
+    assert _joined(strided) == strided
+    # the schedule as a whole still reproduces the reference's known answer (tests/test_minibatch.py:18-25)
+    np.random.seed(42)
+    nmf = TransformInvariantNMF(n_atoms=10, atom_shape=(7, 7), backend=OracleBackend(hooks=False), use_fused_updates=False)
+    nmf.fit_minibatches(racoon_patches_V(), sparsity_H=0.1, algorithm=MiniBatchAlgorithm.GSG_MU, batch_size=3, n_epochs=5,
+                        sag_lambda=0.8)
+    assert np.isclose(nmf._energy_function(), 14223.14454)
