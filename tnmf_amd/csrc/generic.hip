@@ -174,7 +174,11 @@ __global__ __launch_bounds__(kBlock) void k_reconstruct(Geo g, Tile t, const T *
 // quarter of the serial chain.  Rows of H may be padded (g.Hs).
 constexpr int kSmallTY = 2, kSmallTX = 32, kSmallQ = 4;
 
-template <typename T>
+// (kSmallQ = waves per workgroup.  The launched kernel takes up to SIXTEEN -- one atom per wave, one round: with four, the
+// ten atoms of the reference's mini-batch geometry were three serial rounds of load -> LDS -> 49 multiply-adds, 12 us of
+// the 46 us of KERNEL time of a 47 us batch step (rocprof, round 4: the step is not launch bound -- the gaps between its
+// five kernels are 2.9 us on average); the persistent schedule kernel, whose workgroups are four waves, stays at four)
+template <typename T, int kSmallQ = 4>
 __device__ __forceinline__ void reconstruct_small_block(const Geo &g, int tiles_y, int tiles_x, unsigned bid,
                                                         const T *__restrict__ W, const T *__restrict__ H,
                                                         T *__restrict__ R, unsigned char *smem_raw) {
@@ -251,19 +255,24 @@ __device__ __forceinline__ void reconstruct_small_block(const Geo &g, int tiles_
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_reconstruct_small(Geo g, int tiles_y, int tiles_x, const T *__restrict__ W,
+template <typename T, int Q>
+__global__ __launch_bounds__(64 * Q) void k_reconstruct_small(Geo g, int tiles_y, int tiles_x, const T *__restrict__ W,
                                                               const T *__restrict__ H, T *__restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    reconstruct_small_block<T>(g, tiles_y, tiles_x, blockIdx.x, W, H, R, smem_raw);
+    reconstruct_small_block<T, Q>(g, tiles_y, tiles_x, blockIdx.x, W, H, R, smem_raw);
+}
+
+// LDS of the small-call form with q waves per workgroup
+template <typename T>
+inline size_t reconstruct_small_lds(const Geo &g, int q) {
+    return ((size_t)q * ((size_t)(kSmallTY + g.Ay - 1) * (kSmallTX + g.Ax - 1) + (size_t)g.Ay * g.Ax) + (size_t)q * 64) * sizeof(T);
 }
 
 // whether a reconstruct call of this geometry takes the small-call form (launch_reconstruct and the schedule kernel agree)
 template <typename T>
 inline bool reconstruct_is_small(const Geo &g, const Tile &t, size_t *lds_small) {
     const size_t blocks = (size_t)g.N * g.C * t.tiles_y * t.tiles_x;
-    *lds_small = ((size_t)kSmallQ * ((size_t)(kSmallTY + g.Ay - 1) * (kSmallTX + g.Ax - 1) + (size_t)g.Ay * g.Ax) +
-                  (size_t)kSmallQ * 64) * sizeof(T);
+    *lds_small = reconstruct_small_lds<T>(g, kSmallQ);
     return blocks < 64 && g.M >= kSmallQ && g.Dy > 1 && *lds_small <= 64 * 1024;
 }
 
@@ -580,8 +589,23 @@ __global__ __launch_bounds__(kBlock) void k_finalize_blend_apply(int MC, int nA,
     const int total = MC * nA;
     for (int sh = threadIdx.x; sh < nA; sh += kBlock) {
         const int e = (int)r * nA + sh;
+        // (same order of additions; the loads of four partials are in flight together instead of one round trip each)
         double sn = 0.0, sp = 0.0;
-        for (int p = 0; p < P; ++p) {
+        int p = 0;
+        for (; p + 4 <= P; p += 4) {
+            double vn[4], vp[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vn[k] = partials[((size_t)(p + k) * total + e) * 2 + 0];
+                vp[k] = partials[((size_t)(p + k) * total + e) * 2 + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sn += vn[k];
+                sp += vp[k];
+            }
+        }
+        for (; p < P; ++p) {
             sn += partials[((size_t)p * total + e) * 2 + 0];
             sp += partials[((size_t)p * total + e) * 2 + 1];
         }
@@ -792,9 +816,18 @@ int launch_reconstruct(const Geo &g, const void *W, const void *H, void *R, hipS
     size_t lds_small = 0;
     if (reconstruct_is_small<T>(g, t, &lds_small)) {
         // a small call (a mini-batch of a few samples): four waves per tile of 2 x 32 pixels, each on its own atoms
+        // waves per workgroup: one atom per wave where that fits (up to 16 waves and 64 KB of LDS), else rounds of 8 or 4
         const int tiles_y = cdiv(g.Dy, kSmallTY), tiles_x = cdiv(g.Dx, kSmallTX);
-        hipLaunchKernelGGL(k_reconstruct_small<T>, dim3((unsigned)((size_t)g.N * g.C * tiles_y * tiles_x)), dim3(kBlock),
-                           lds_small, s, g, tiles_y, tiles_x, (const T *)W, (const T *)H, (T *)R);
+        const dim3 grid((unsigned)((size_t)g.N * g.C * tiles_y * tiles_x));
+        if (g.M > 8 && reconstruct_small_lds<T>(g, 16) <= 64 * 1024)
+            hipLaunchKernelGGL((k_reconstruct_small<T, 16>), grid, dim3(64 * 16), reconstruct_small_lds<T>(g, 16), s, g, tiles_y,
+                               tiles_x, (const T *)W, (const T *)H, (T *)R);
+        else if (g.M > 4 && reconstruct_small_lds<T>(g, 8) <= 64 * 1024)
+            hipLaunchKernelGGL((k_reconstruct_small<T, 8>), grid, dim3(64 * 8), reconstruct_small_lds<T>(g, 8), s, g, tiles_y,
+                               tiles_x, (const T *)W, (const T *)H, (T *)R);
+        else
+            hipLaunchKernelGGL((k_reconstruct_small<T, 4>), grid, dim3(kBlock), lds_small, s, g, tiles_y, tiles_x,
+                               (const T *)W, (const T *)H, (T *)R);
         TNMF_LAUNCH_CHECK();
         return TNMF_OK;
     }
