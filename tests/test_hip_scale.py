@@ -563,6 +563,39 @@ def test_bench_two_rank_path_rehearsal(tmp_path):
     assert line['rccl_ranks_seen'] == 2 and line['distributed']['backend'] == 'gloo'
 
 
+def test_bench_line_contract():
+    """The one JSON line of `python bench.py` (here on BASELINE config 2, a few steps, a two-second CPU leg): the keys the
+    driver reads, the roofline object of the dominant kernel (algorithmic work / measured launch time against the peak, PMC
+    traffic from the committed profile with its staleness stamp) and the CPU baseline timed on this box's host cores."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', '2', '--steps', '4', '--warmup', '1',
+                          '--cpu-budget', '2', '--no-fft-variant'], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config']
+    assert abs(d['value'] - 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
+    assert 'k_split_corr_W' in r['kernel'] and r['avg_launch_ms'] > 0
+    assert r['traffic'] is None or r['traffic'] > 0
+    assert r['traffic_file_is_current'] in (True, False, None) and r['rocprof_file_is_current'] in (True, False, None)
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] == os.cpu_count() and c['value'] > 0 and 'samples' in c['sample']
+    p = d['parity']
+    assert p['W_rel_diff_vs_oracle'] < 1e-5 and p['H_rel_diff_vs_oracle'] < 1e-5 and p['energy_gap_vs_oracle'] < 1e-5
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """The form the driver's SCALE run takes: plain `python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment.
     bench.py starts the two ranks itself as CHILD processes (torch.distributed.run) before it touches the GPU and relays
